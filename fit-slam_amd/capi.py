@@ -1,0 +1,289 @@
+"""ctypes binding of include/fitslam_frontier.h (libfitslam_frontier.so).
+
+This is the thin Python host layer over the C ABI: it owns no algorithm.  There is no CPU
+fallback — if the HIP library cannot be built/loaded or no gfx950 device is present, creating a
+`FrontierScorer` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+FS_OK, FS_E_INVALID, FS_E_NO_DEVICE, FS_E_HIP, FS_E_STATE, FS_E_IO, FS_E_RANGE = 0, -1, -2, -3, -4, -5, -6
+STATUS_OK, STATUS_OFF_MAP, STATUS_BLACKLISTED = 0, 1, 2
+FS_MAX_ELEV = 16
+
+# every symbol include/fitslam_frontier.h declares
+EXPORTED_SYMBOLS = [
+    "fs_abi_version", "fs_ctx_create", "fs_ctx_destroy", "fs_last_error", "fs_synchronize",
+    "fs_enable_kernel_timing", "fs_kernel_time",
+    "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_max_arrival", "fs_set_arrival_limits",
+    "fs_score_arrival",
+    "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
+    "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim",
+    "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_selftest_fp64",
+]
+
+RECORD_DTYPE = np.dtype([("arrival", "<i4"), ("argmax", "<i4"), ("yaw", "<f4"), ("info_ref", "<f4"),
+                         ("trace", "<f4"), ("logdet", "<f4"), ("n_visible", "<i4"), ("flags", "<u4")])
+assert RECORD_DTYPE.itemsize == 32
+
+
+class RayParamsC(C.Structure):
+    _fields_ = [("max_camera_depth", C.c_double), ("delta_theta", C.c_double), ("camera_fov", C.c_double),
+                ("robot_radius", C.c_double), ("n_rays", C.c_int32), ("n_elev", C.c_int32),
+                ("elev", C.c_double * FS_MAX_ELEV),
+                ("obst_min", C.c_int32), ("obst_max", C.c_int32), ("trace_min", C.c_int32), ("trace_max", C.c_int32),
+                ("factor_max", C.c_double), ("factor_min", C.c_double), ("polygon", C.c_double * 4)]
+
+
+class FimParamsC(C.Structure):
+    _fields_ = [("max_dist", C.c_double), ("max_angle", C.c_double)]
+
+
+class FsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fitslam_frontier error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(build: bool = True):
+    """Load (building first if needed) the HIP library.  Raises if it is missing: no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build and _build.needs_build():
+        path = _build.build()
+    if not os.path.exists(path):
+        raise FsError(FS_E_NO_DEVICE, f"{path} is missing and could not be built; there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.fs_abi_version.restype = C.c_int
+    L.fs_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.fs_ctx_destroy.argtypes = [vp]
+    L.fs_ctx_destroy.restype = None
+    L.fs_last_error.argtypes = [vp]
+    L.fs_last_error.restype = C.c_char_p
+    L.fs_synchronize.argtypes = [vp]
+    L.fs_enable_kernel_timing.argtypes = [vp, C.c_int]
+    L.fs_kernel_time.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64)]
+    L.fs_set_ray_params.argtypes = [vp, C.POINTER(RayParamsC)]
+    L.fs_ray_fan_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.fs_upload_grid.argtypes = [vp, vp, i32, i32, i32, C.POINTER(dbl * 3), dbl]
+    L.fs_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
+    L.fs_set_arrival_limits.argtypes = [vp, dbl, dbl]
+    L.fs_score_arrival.argtypes = [vp, i32] + [vp] * 10
+    L.fs_upload_landmarks.argtypes = [vp, vp, i32]
+    L.fs_lookup_generate.argtypes = [vp, vp]
+    L.fs_lookup_load.argtypes = [vp, C.c_char_p]
+    L.fs_lookup_save.argtypes = [vp, C.c_char_p]
+    L.fs_lookup_set_records.argtypes = [vp, vp, i64]
+    L.fs_lookup_num_records.argtypes = [vp, C.POINTER(i64)]
+    L.fs_lookup_get_records.argtypes = [vp, vp]
+    L.fs_lookup_query.argtypes = [vp, vp, C.POINTER(C.c_float)]
+    L.fs_set_fim_params.argtypes = [vp, C.POINTER(FimParamsC)]
+    L.fs_score_fim.argtypes = [vp, i32] + [vp] * 7
+    L.fs_score_candidates.argtypes = [vp, i32] + [vp] * 5
+    L.fs_score_candidates_dev.argtypes = [vp, i32] + [vp] * 5
+    L.fs_rank_candidates.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp]
+    L.fs_selftest_fp64.argtypes = [vp, i32, C.POINTER(i64)]
+    for name in EXPORTED_SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("fs_ctx_destroy", "fs_last_error"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class FrontierScorer:
+    """One scoring context = one GPU + one HIP stream.  Mirrors the call order of the reference:
+    construct (parameters) -> grid snapshot -> max-arrival calibration -> score."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.fs_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != FS_OK:
+            raise FsError(rc, "fs_ctx_create failed: no gfx950 device / HIP runtime (no CPU fallback exists)")
+        self._h = h
+        self._elev = (0.0,)
+        self.n_yaw = self.n_elev = self.window = 0
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc != FS_OK:
+            raise FsError(rc, (self._L.fs_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._check(self._L.fs_synchronize(self._h))
+
+    def enable_kernel_timing(self, on=True):
+        self._check(self._L.fs_enable_kernel_timing(self._h, 1 if on else 0))
+
+    def kernel_time(self, kind: int):
+        ms, cnt = C.c_double(), C.c_int64()
+        self._check(self._L.fs_kernel_time(self._h, kind, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    # -- arrival information
+    def set_ray_params(self, max_camera_depth=2.0, delta_theta=0.10, camera_fov=1.04, robot_radius=0.60,
+                       n_rays=0, elev=(0.0,), obst=(240, 254), trace=(255, 255), factor_max=1.2,
+                       factor_min=0.70, polygon=(-1e300, -1e300, 1e300, 1e300)):
+        p = RayParamsC()
+        p.max_camera_depth, p.delta_theta, p.camera_fov, p.robot_radius = max_camera_depth, delta_theta, camera_fov, robot_radius
+        p.n_rays, p.n_elev = int(n_rays), len(elev)
+        for i, e in enumerate(elev[:FS_MAX_ELEV]):
+            p.elev[i] = float(e)
+        p.obst_min, p.obst_max, p.trace_min, p.trace_max = int(obst[0]), int(obst[1]), int(trace[0]), int(trace[1])
+        p.factor_max, p.factor_min = factor_max, factor_min
+        for i in range(4):
+            p.polygon[i] = float(polygon[i])
+        self._check(self._L.fs_set_ray_params(self._h, C.byref(p)))
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._L.fs_ray_fan_shape(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.n_yaw, self.n_elev, self.window = a.value, b.value, c.value
+
+    def upload_grid(self, cells: np.ndarray, origin, resolution: float):
+        c = np.ascontiguousarray(cells, dtype=np.uint8)
+        if c.ndim == 2:
+            c = c[None]
+        nz, ny, nx = c.shape
+        o = (C.c_double * 3)(*[float(v) for v in origin])
+        self._check(self._L.fs_upload_grid(self._h, _p(c), nx, ny, nz, C.byref(o), float(resolution)))
+
+    def max_arrival(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._L.fs_max_arrival(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(max_value=a.value, max_gt=b.value, min_gt=c.value)
+
+    def set_arrival_limits(self, max_gt, min_gt):
+        self._check(self._L.fs_set_arrival_limits(self._h, float(max_gt), float(min_gt)))
+
+    def score_arrival(self, goal_xyz, frontier_size=None, blacklisted=None, achievable_in=None, want_ray_counts=True):
+        goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+        n = goal.shape[0]
+        fs = None if frontier_size is None else np.ascontiguousarray(frontier_size, dtype=np.int32)
+        bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+        ai = None if achievable_in is None else np.ascontiguousarray(achievable_in, dtype=np.uint8)
+        rc_arr = np.zeros((n, self.n_elev, self.n_yaw), dtype=np.int32) if want_ray_counts else None
+        arrival = np.zeros(n, dtype=np.int32); argmax = np.zeros(n, dtype=np.int32)
+        yaw = np.zeros(n, dtype=np.float64); ach = np.zeros(n, dtype=np.uint8); status = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_score_arrival(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(rc_arr),
+                                             _p(arrival), _p(argmax), _p(yaw), _p(ach), _p(status)))
+        return dict(ray_counts=rc_arr, arrival=arrival, argmax=argmax, yaw=yaw, achievable=ach, status=status)
+
+    # -- Fisher information
+    def upload_landmarks(self, xyz):
+        lm = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self._check(self._L.fs_upload_landmarks(self._h, _p(lm), lm.shape[0]))
+
+    def lookup_generate(self, bounds=None):
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.float32)
+        self._check(self._L.fs_lookup_generate(self._h, _p(b)))
+
+    def lookup_load(self, path: str):
+        self._check(self._L.fs_lookup_load(self._h, path.encode()))
+
+    def lookup_save(self, path: str):
+        self._check(self._L.fs_lookup_save(self._h, path.encode()))
+
+    def lookup_set_records(self, records):
+        r = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 4)
+        self._check(self._L.fs_lookup_set_records(self._h, _p(r), r.shape[0]))
+
+    def lookup_records(self) -> np.ndarray:
+        n = C.c_int64()
+        self._check(self._L.fs_lookup_num_records(self._h, C.byref(n)))
+        out = np.zeros((n.value, 4), dtype=np.float32)
+        self._check(self._L.fs_lookup_get_records(self._h, _p(out)))
+        return out
+
+    def lookup_query(self, p) -> float:
+        a = np.ascontiguousarray(p, dtype=np.float32)
+        v = C.c_float()
+        self._check(self._L.fs_lookup_query(self._h, _p(a), C.byref(v)))
+        return v.value
+
+    def set_fim_params(self, max_dist=14.0, max_angle=1.0):
+        p = FimParamsC(max_dist, max_angle)
+        self._check(self._L.fs_set_fim_params(self._h, C.byref(p)))
+
+    def score_fim(self, pose7, want_fim=True):
+        ps = np.ascontiguousarray(pose7, dtype=np.float64).reshape(-1, 7)
+        n = ps.shape[0]
+        info = np.zeros(n, dtype=np.float32)
+        fim21 = np.zeros((n, 21), dtype=np.float32) if want_fim else None
+        trace = np.zeros(n, dtype=np.float32); logdet = np.zeros(n, dtype=np.float32)
+        nvis = np.zeros(n, dtype=np.int32); nvox = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_score_fim(self._h, n, _p(ps), _p(info), _p(fim21), _p(trace), _p(logdet), _p(nvis), _p(nvox)))
+        return dict(info_ref=info, fim21=fim21, trace=trace, logdet=logdet, n_visible=nvis, n_voxels=nvox)
+
+    # -- fused
+    def score_candidates(self, goal_xyz, frontier_size=None, blacklisted=None, achievable_in=None) -> np.ndarray:
+        goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+        n = goal.shape[0]
+        fs = None if frontier_size is None else np.ascontiguousarray(frontier_size, dtype=np.int32)
+        bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+        ai = None if achievable_in is None else np.ascontiguousarray(achievable_in, dtype=np.uint8)
+        rec = np.zeros(n, dtype=RECORD_DTYPE)
+        self._check(self._L.fs_score_candidates(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(rec)))
+        return rec
+
+    def score_candidates_dev(self, n, d_goal, d_fsize, d_black, d_achin, d_records):
+        """Device-pointer form (ints from tensor.data_ptr()); asynchronous on the context's stream."""
+        vp = C.c_void_p
+        self._check(self._L.fs_score_candidates_dev(self._h, int(n), vp(d_goal), vp(d_fsize) if d_fsize else None,
+                                                    vp(d_black) if d_black else None,
+                                                    vp(d_achin) if d_achin else None, vp(d_records)))
+
+    def rank_candidates(self, records, path_length, path_heading, blacklisted=None,
+                        alpha=0.25, beta=1.0, max_vx=0.5, max_wz=0.5):
+        rec = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        n = rec.shape[0]
+        pl = np.ascontiguousarray(path_length, dtype=np.float64)
+        ph = np.ascontiguousarray(path_heading, dtype=np.float64)
+        bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+        cost = np.zeros(n); au = np.zeros(n); du = np.zeros(n); order = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_rank_candidates(self._h, n, _p(rec), _p(bl), _p(pl), _p(ph), alpha, beta, max_vx, max_wz,
+                                               _p(cost), _p(au), _p(du), _p(order)))
+        return dict(weighted_cost=cost, arrival_utility=au, distance_utility=du, order=order)
+
+    def selftest_fp64(self, max_abs=256) -> int:
+        bad = C.c_int64()
+        self._check(self._L.fs_selftest_fp64(self._h, int(max_abs), C.byref(bad)))
+        return bad.value
+
+
+def record_status(rec):
+    return (rec["flags"] >> 8) & 0xFF
+
+
+def record_achievable(rec):
+    return (rec["flags"] & 1).astype(np.uint8)
+
+
+def record_nvoxels(rec):
+    return (rec["flags"] >> 16) & 0xFFFF

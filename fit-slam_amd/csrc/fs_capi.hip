@@ -1,0 +1,982 @@
+// fs_capi.hip — the C ABI of include/fitslam_frontier.h: context, staging of grid / landmarks / lookup
+// table into HBM, host-side precomputation (fan directions, yaw rotations, crowding factors, dense
+// table) and the launch sequences.  No CPU compute fallback exists: every scoring entry point
+// launches the HIP kernels of fs_raymarch.hip / fs_fim.hip / fs_rank.hip or fails.
+#include "fs_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *d_black,
+                          const double *d_len, const double *d_head, double alpha, double beta,
+                          double max_vx, double max_wz, double max_gt, double *d_cost, double *d_au,
+                          double *d_du, int32_t *d_order, int32_t *d_err, void **scratch, size_t *scratch_bytes,
+                          hipStream_t s);
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = std::max<size_t>(n, 64);
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+};
+
+struct TimedLaunch {
+    int kind;
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct fs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // ray parameters
+    bool have_ray = false;
+    fs_ray_params rp{};
+    int32_t n_yaw = 0, n_elev = 0, window = 0;
+    DevBuf<double> d_dir;
+    DevBuf<float> d_yawR;
+    double max_gt = 0.0, min_gt = 0.0;
+
+    // grid
+    bool have_grid = false;
+    DevBuf<uint8_t> d_cells;
+    int32_t nx = 0, ny = 0, nz = 0;
+    double origin[3] = {0, 0, 0};
+    double res = 0.0;
+
+    // landmarks
+    bool have_lm = false;
+    int32_t m = 0, m_padded = 0;
+    DevBuf<float> d_lx, d_ly, d_lz;
+
+    // lookup table
+    bool have_table = false;
+    std::vector<float> records;           // as in the .dat, [n][4]
+    std::vector<float> dense;             // host copy of the dense table
+    int32_t jx0 = 0, jy0 = 0, jz0 = 0, tx = 0, ty = 0, tz = 0;
+    DevBuf<float> d_table, d_factor;
+    bool have_factor = false;
+
+    // fim parameters
+    fs_fim_params fp{14.0, 1.0};
+
+    // hash tables
+    DevBuf<uint32_t> d_gtable;
+    int ghash_bits = 0;
+    static constexpr int kPool = 128;
+
+    // per-candidate scratch
+    DevBuf<double> d_goal, d_yaw, d_len, d_head, d_cost, d_au, d_du, d_sums;
+    DevBuf<int32_t> d_fsize, d_arrival, d_argmax, d_status, d_nvis, d_nvox, d_raycounts, d_order, d_err;
+    DevBuf<uint8_t> d_black, d_achin, d_ach;
+    DevBuf<float> d_info, d_trace, d_logdet, d_fim21, d_Rt;
+    DevBuf<uint32_t> d_overflow;
+    DevBuf<fs_record> d_records;
+    void *rank_scratch = nullptr;
+    size_t rank_scratch_bytes = 0;
+
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> launches;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(fs_ctx *c, int code, const char *fmt, ...)
+{
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define FS_HIP(c, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) return fail((c), FS_E_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+double std_min(double a, double b) { return (b < a) ? b : a; }
+double std_max(double a, double b) { return (a < b) ? b : a; }
+
+hipEvent_t get_event(fs_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer {
+    fs_ctx *c;
+    TimedLaunch t{};
+    bool on;
+    ScopedTimer(fs_ctx *ctx, int kind) : c(ctx), on(ctx->timing)
+    {
+        if (!on) return;
+        t.kind = kind;
+        t.start = get_event(c);
+        t.stop = get_event(c);
+        (void)hipEventRecord(t.start, c->stream);
+    }
+    ~ScopedTimer()
+    {
+        if (!on) return;
+        (void)hipEventRecord(t.stop, c->stream);
+        c->launches.push_back(t);
+    }
+};
+
+// ---------------------------------------------------------------- lookup-table math (host, float32)
+// FIP/src/fisher_information/FisherInformationHelpers.cpp:71-96,114-123 with Q = I.
+float information_of_point_local(const float p[3])
+{
+    const float n = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    const float inv_n = 1 / n, inv_n3 = 1 / (n * n * n);
+    float dfdp[3][3], right[3][6], jac[3][6];
+    for (int r = 0; r < 3; ++r)
+        for (int col = 0; col < 3; ++col) dfdp[r][col] = inv_n * (r == col ? 1.0f : 0.0f) - (inv_n3 * p[r]) * p[col];
+    const float skew[3][3] = {{0, -p[2], p[1]}, {p[2], 0, -p[0]}, {-p[1], p[0], 0}};
+    for (int r = 0; r < 3; ++r)
+        for (int col = 0; col < 3; ++col) {
+            right[r][col] = (float)(-1.0) * (r == col ? 1.0f : 0.0f);
+            right[r][col + 3] = skew[r][col];
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int col = 0; col < 6; ++col) {
+            float acc = 0.0f;
+            for (int k = 0; k < 3; ++k) acc += dfdp[r][k] * right[k][col];
+            jac[r][col] = acc;
+        }
+    float trace = 0.0f;
+    for (int col = 0; col < 6; ++col) {
+        float acc = 0.0f;
+        for (int k = 0; k < 3; ++k) acc += jac[k][col] * jac[k][col];
+        trace += acc;
+    }
+    return trace;
+}
+
+const float kStepMin = 0.09f, kStepMax = 0.3f, kSubSampleUntil = -1.0f;   // FisherInfoManager.hpp:25-30
+
+// FisherInfoManager.hpp:108-123
+void voxel_coordinate(float x, float y, float z, float key[3], long lattice[3])
+{
+    double step;
+    if (std::fabs(x) < kSubSampleUntil && std::fabs(y) < kSubSampleUntil && std::fabs(z) < kSubSampleUntil) step = kStepMin;
+    else step = kStepMax;
+    const double r[3] = {std::round(x * (1 / step)), std::round(y * (1 / step)), std::round(z * (1 / step))};
+    for (int i = 0; i < 3; ++i) {
+        key[i] = (float)(r[i] * step);
+        if (lattice) lattice[i] = (long)r[i];
+    }
+}
+
+struct KeyBits {
+    uint32_t b[3];
+    bool operator==(const KeyBits &o) const { return b[0] == o.b[0] && b[1] == o.b[1] && b[2] == o.b[2]; }
+};
+struct KeyBitsHash {
+    size_t operator()(const KeyBits &k) const
+    {
+        size_t h = 0;
+        for (uint32_t v : k.b) h ^= std::hash<uint32_t>{}(v) + 0x9e3779b9 + (h << 6) + (h >> 2);
+        return h;
+    }
+};
+KeyBits key_bits(const float k[3])
+{
+    KeyBits out;
+    for (int i = 0; i < 3; ++i) {
+        float f = (k[i] == 0.0f) ? 0.0f : k[i];     // -0 == +0 under float equality
+        std::memcpy(&out.b[i], &f, 4);
+    }
+    return out;
+}
+
+// FisherInfoManager.cpp:117-229 — produces the file's record sequence.
+void generate_records(float minX, float maxX, float minY, float maxY, float minZ, float maxZ, std::vector<float> &rec)
+{
+    rec.clear();
+    float max_fi = -std::numeric_limits<float>::max();
+    minX = std::floor(minX * (1 / kStepMax)) * kStepMax;
+    minY = std::floor(minY * (1 / kStepMax)) * kStepMax;
+    minZ = std::floor(minZ * (1 / kStepMax)) * kStepMax;
+    maxX = std::ceil(maxX * (1 / kStepMax)) * kStepMax;
+    maxY = std::ceil(maxY * (1 / kStepMax)) * kStepMax;
+    maxZ = std::ceil(maxZ * (1 / kStepMax)) * kStepMax;
+    std::unordered_set<KeyBits, KeyBitsHash> existing;
+    float inc = kStepMin;
+    for (float cx = minX; cx <= maxX; cx += inc) {
+        if (cx > kSubSampleUntil + kStepMax) inc = kStepMax;
+        for (float cy = minY; cy <= maxY; cy += inc) {
+            for (float cz = minZ; cz <= maxZ; cz += inc) {
+                float key[3];
+                voxel_coordinate(cx, cy, cz, key, nullptr);
+                if (!existing.insert(key_bits(key)).second) continue;
+                const float value = information_of_point_local(key);
+                if (std::isnan(value)) continue;
+                max_fi = std::max(max_fi, value);
+                rec.insert(rec.end(), {key[0], key[1], key[2], value});
+            }
+        }
+    }
+    rec.insert(rec.end(), {0.0f, 0.0f, 0.0f, max_fi});
+}
+
+// Dense re-indexing of the record list by the integer voxel lattice (what loadLookupTable's
+// unordered_map resolves to: later duplicates overwrite, FisherInfoManager.cpp:245-251).
+int build_dense(fs_ctx *c)
+{
+    const int64_t n = (int64_t)c->records.size() / 4;
+    if (n <= 0) return fail(c, FS_E_INVALID, "lookup table has no records");
+    const double step = (double)kStepMax, inv = 1 / step;
+    long lo[3] = {LONG_MAX, LONG_MAX, LONG_MAX}, hi[3] = {LONG_MIN, LONG_MIN, LONG_MIN};
+    std::vector<long> lat((size_t)n * 3);
+    for (int64_t i = 0; i < n; ++i) {
+        const float *r = &c->records[4 * i];
+        for (int a = 0; a < 3; ++a) {
+            const long j = std::lround((double)r[a] * inv);
+            const float back = (float)((double)j * step);
+            if (!(back == r[a])) return fail(c, FS_E_INVALID, "lookup record %lld is off the 0.3 m voxel lattice", (long long)i);
+            lat[3 * i + a] = j;
+            lo[a] = std::min(lo[a], j);
+            hi[a] = std::max(hi[a], j);
+        }
+    }
+    const int64_t dx = hi[0] - lo[0] + 1, dy = hi[1] - lo[1] + 1, dz = hi[2] - lo[2] + 1;
+    if (dx * dy * dz > (int64_t)FS_MAX_TABLE_CELLS) return fail(c, FS_E_INVALID, "lookup table lattice too large (%lld cells)", (long long)(dx * dy * dz));
+    c->jx0 = (int32_t)lo[0]; c->jy0 = (int32_t)lo[1]; c->jz0 = (int32_t)lo[2];
+    c->tx = (int32_t)dx; c->ty = (int32_t)dy; c->tz = (int32_t)dz;
+    c->dense.assign((size_t)(dx * dy * dz), std::numeric_limits<float>::quiet_NaN());
+    for (int64_t i = 0; i < n; ++i) {
+        const size_t idx = ((size_t)(lat[3 * i] - lo[0]) * dy + (size_t)(lat[3 * i + 1] - lo[1])) * dz + (size_t)(lat[3 * i + 2] - lo[2]);
+        c->dense[idx] = c->records[4 * i + 3];
+    }
+    FS_HIP(c, c->d_table.ensure(c->dense.size()));
+    FS_HIP(c, hipMemcpyAsync(c->d_table.p, c->dense.data(), c->dense.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (!c->have_factor) {
+        // getFactorFromNum(num, 0.8f) — FisherInfoManager.hpp:102-106 (pow/exp in double, float return)
+        std::vector<float> fac(FS_FACTOR_N, 0.0f);
+        const float s = 0.8f;
+        for (int k = 1; k < FS_FACTOR_N; ++k) fac[k] = (float)std::exp(1 - std::pow((double)k, (double)s));
+        FS_HIP(c, c->d_factor.ensure(fac.size()));
+        FS_HIP(c, hipMemcpyAsync(c->d_factor.p, fac.data(), fac.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        FS_HIP(c, hipStreamSynchronize(c->stream));
+        c->have_factor = true;
+    }
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_table = true;
+    return FS_OK;
+}
+
+// getTransformFromPose (FisherInformationHelpers.cpp:16-26): float translation, Eigen::Quaternionf -> rotation.
+void pose_to_rt(const double pose7[7], float Rt[12])
+{
+    const float x = (float)pose7[3], y = (float)pose7[4], z = (float)pose7[5], w = (float)pose7[6];
+    const float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+    const float twx = tx * w, twy = ty * w, twz = tz * w;
+    const float txx = tx * x, txy = ty * x, txz = tz * x;
+    const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    Rt[0] = 1.0f - (tyy + tzz); Rt[1] = txy - twz;          Rt[2] = txz + twy;
+    Rt[3] = txy + twz;          Rt[4] = 1.0f - (txx + tzz); Rt[5] = tyz - twx;
+    Rt[6] = txz - twy;          Rt[7] = tyz + twx;          Rt[8] = 1.0f - (txx + tyy);
+    Rt[9] = (float)pose7[0]; Rt[10] = (float)pose7[1]; Rt[11] = (float)pose7[2];
+}
+
+int check_scoring_state(fs_ctx *c, bool need_rays, bool need_fim)
+{
+    if (need_rays && !c->have_ray) return fail(c, FS_E_STATE, "fs_set_ray_params has not been called");
+    if (need_rays && !c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
+    if (need_fim && !c->have_lm) return fail(c, FS_E_STATE, "fs_upload_landmarks has not been called");
+    if (need_fim && !c->have_table) return fail(c, FS_E_STATE, "no lookup table: call fs_lookup_generate / fs_lookup_load");
+    return FS_OK;
+}
+
+int fill_ray_args(fs_ctx *c, FsRayArgs &a)
+{
+    const fs_ray_params &p = c->rp;
+    a.grid = FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res};
+    a.dir = c->d_dir.p;
+    a.n_yaw = c->n_yaw; a.n_elev = c->n_elev; a.window = c->window;
+    a.max_length = (unsigned int)(p.max_camera_depth / c->res);             // CostCalculator.cpp:28
+    a.obst_min = p.obst_min; a.obst_max = p.obst_max; a.trace_min = p.trace_min; a.trace_max = p.trace_max;
+    a.clamp = 1;
+    // CostCalculator.cpp:47-48, getSizeInMeters = (size - 1 + 0.5) * resolution
+    const double smx = (c->nx - 1 + 0.5) * c->res, smy = (c->ny - 1 + 0.5) * c->res, smz = (c->nz - 1 + 0.5) * c->res;
+    a.lo_x = std_max(p.polygon[0], c->origin[0]);
+    a.hi_x = std_min(p.polygon[2], c->origin[0] + smx);
+    a.lo_y = std_max(p.polygon[1], c->origin[1]);
+    a.hi_y = std_min(p.polygon[3], c->origin[1] + smy);
+    a.lo_z = c->origin[2];
+    a.hi_z = c->origin[2] + smz;
+    a.footprint_radius = std::ceil(p.robot_radius / c->res);               // CostCalculator.cpp:77
+    a.delta_theta = p.delta_theta;
+    a.half_fov = p.camera_fov / 2;
+    a.min_gt = c->min_gt;
+    return FS_OK;
+}
+
+int fill_fim_args(fs_ctx *c, FsFimArgs &a)
+{
+    a.lx = c->d_lx.p; a.ly = c->d_ly.p; a.lz = c->d_lz.p;
+    a.m_padded = c->m_padded;
+    a.table = c->d_table.p;
+    a.jx0 = c->jx0; a.jy0 = c->jy0; a.jz0 = c->jz0;
+    a.tx = c->tx; a.ty = c->ty; a.tz = c->tz;
+    a.inv_step = 1 / (double)kStepMax;
+    a.factor = c->d_factor.p;
+    a.maxd2 = (float)(c->fp.max_dist * c->fp.max_dist);
+    if (c->fp.max_angle >= M_PI) {
+        a.cone_mode = 0; a.cos2 = 0.0f;
+    } else {
+        const float cs = (float)std::cos(c->fp.max_angle);
+        a.cos2 = cs * cs;
+        a.cone_mode = (cs >= 0.0f) ? 1 : 2;
+    }
+    // LDS table: enough for every landmark to sit in its own voxel when the cloud is small,
+    // otherwise 2^15 slots (128 KiB of the CU's 160 KiB); fuller candidates take the HBM-table pass
+    int bits = 10;
+    while (bits < 15 && (1 << bits) < 2 * c->m) ++bits;
+    a.hash_bits = bits;
+    a.gtable = c->d_gtable.p;
+    a.ghash_bits = c->ghash_bits;
+    return FS_OK;
+}
+
+int ensure_candidate_scratch(fs_ctx *c, size_t n, bool want_fim21)
+{
+    FS_HIP(c, c->d_arrival.ensure(n)); FS_HIP(c, c->d_argmax.ensure(n)); FS_HIP(c, c->d_status.ensure(n));
+    FS_HIP(c, c->d_yaw.ensure(n)); FS_HIP(c, c->d_ach.ensure(n));
+    FS_HIP(c, c->d_info.ensure(n)); FS_HIP(c, c->d_trace.ensure(n)); FS_HIP(c, c->d_logdet.ensure(n));
+    FS_HIP(c, c->d_nvis.ensure(n)); FS_HIP(c, c->d_nvox.ensure(n)); FS_HIP(c, c->d_overflow.ensure(n));
+    FS_HIP(c, c->d_sums.ensure(n * 18));
+    if (want_fim21) FS_HIP(c, c->d_fim21.ensure(n * 21));
+    return FS_OK;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+
+extern "C" {
+
+int fs_abi_version(void) { return FS_ABI_VERSION; }
+
+int fs_ctx_create(int device_id, void *stream, fs_ctx **out)
+{
+    if (!out) return FS_E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return FS_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return FS_E_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FS_E_NO_DEVICE;   // kernels are built for gfx950 only
+    if (hipSetDevice(device_id) != hipSuccess) return FS_E_NO_DEVICE;
+    fs_ctx *c = new fs_ctx();
+    c->device = device_id;
+    if (stream) {
+        c->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return FS_E_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return FS_OK;
+}
+
+void fs_ctx_destroy(fs_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &t : c->launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release();
+    c->d_lx.release(); c->d_ly.release(); c->d_lz.release();
+    c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
+    c->d_goal.release(); c->d_yaw.release(); c->d_len.release(); c->d_head.release();
+    c->d_cost.release(); c->d_au.release(); c->d_du.release(); c->d_sums.release();
+    c->d_fsize.release(); c->d_arrival.release(); c->d_argmax.release(); c->d_status.release();
+    c->d_nvis.release(); c->d_nvox.release(); c->d_raycounts.release(); c->d_order.release(); c->d_err.release();
+    c->d_black.release(); c->d_achin.release(); c->d_ach.release();
+    c->d_info.release(); c->d_trace.release(); c->d_logdet.release(); c->d_fim21.release(); c->d_Rt.release();
+    c->d_overflow.release(); c->d_records.release();
+    if (c->rank_scratch) (void)hipFree(c->rank_scratch);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *fs_last_error(const fs_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int fs_synchronize(fs_ctx *c)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    return FS_OK;
+}
+
+int fs_enable_kernel_timing(fs_ctx *c, int enable)
+{
+    if (!c) return FS_E_INVALID;
+    c->timing = enable != 0;
+    return FS_OK;
+}
+
+int fs_kernel_time(fs_ctx *c, int kind, double *total_ms, int64_t *launches)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    int64_t cnt = 0;
+    std::vector<TimedLaunch> keep;
+    for (auto &t : c->launches) {
+        if (t.kind == kind) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) { tot += ms; ++cnt; }
+            c->event_pool.push_back(t.start);
+            c->event_pool.push_back(t.stop);
+        } else {
+            keep.push_back(t);
+        }
+    }
+    c->launches.swap(keep);
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = cnt;
+    return FS_OK;
+}
+
+// ------------------------------------------------------------------ arrival information
+
+int fs_set_ray_params(fs_ctx *c, const fs_ray_params *p)
+{
+    if (!c || !p) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (!(p->delta_theta > 0.0) || !(p->max_camera_depth > 0.0) || !(p->camera_fov > 0.0))
+        return fail(c, FS_E_INVALID, "max_camera_depth, delta_theta and camera_fov must be positive");
+    if (p->n_elev < 1 || p->n_elev > FS_MAX_ELEV) return fail(c, FS_E_INVALID, "n_elev must be in [1,%d]", FS_MAX_ELEV);
+    // DEP/src/CostCalculator.cpp:36 — accumulated theta, `theta <= 2*pi`
+    std::vector<double> theta;
+    if (p->n_rays > 0) {
+        double t = 0;
+        for (int i = 0; i < p->n_rays; ++i) { theta.push_back(t); t += p->delta_theta; }
+    } else {
+        for (double t = 0; t <= (2 * M_PI); t += p->delta_theta) {
+            theta.push_back(t);
+            if (theta.size() > 4096) break;
+        }
+    }
+    const int n_yaw = (int)theta.size();
+    const int k = static_cast<int>(p->camera_fov / p->delta_theta);          // :87
+    if (n_yaw > 4096) return fail(c, FS_E_INVALID, "more than 4096 yaw rays");
+    if (k < 1 || n_yaw < k)
+        return fail(c, FS_E_INVALID, "fewer yaw rays (%d) than the FOV window (%d): the reference would build a negative-size vector (CostCalculator.cpp:90)", n_yaw, k);
+    std::vector<double> dir((size_t)n_yaw * p->n_elev * 3);
+    for (int e = 0; e < p->n_elev; ++e) {
+        const double d_h = p->max_camera_depth * std::cos(p->elev[e]);
+        const double d_z = p->max_camera_depth * std::sin(p->elev[e]);
+        for (int i = 0; i < n_yaw; ++i) {
+            double *d = &dir[((size_t)e * n_yaw + i) * 3];
+            d[0] = d_h * std::cos(theta[i]);                                 // :42
+            d[1] = d_h * std::sin(theta[i]);                                 // :43
+            d[2] = d_z;
+        }
+    }
+    // rotation of the pose (goal, best yaw) for every possible argmax: orientationAroundZAxis(yaw)
+    // (setRPY(0,0,yaw)) -> Quaternionf -> rotation matrix, as isPoseSafe(Point,Point) + getTransformFromPose
+    const int n_win = n_yaw - k + 1;
+    std::vector<float> yawR((size_t)n_win * 9);
+    for (int i = 0; i < n_win; ++i) {
+        const double yaw = (i * p->delta_theta) + (p->camera_fov / 2);       // :119
+        const double half = yaw * 0.5;
+        const double pose7[7] = {0, 0, 0, 0.0, 0.0, std::sin(half), std::cos(half)};
+        float Rt[12];
+        pose_to_rt(pose7, Rt);
+        std::copy(Rt, Rt + 9, &yawR[(size_t)i * 9]);
+    }
+    FS_HIP(c, c->d_dir.ensure(dir.size()));
+    FS_HIP(c, c->d_yawR.ensure(yawR.size()));
+    FS_HIP(c, hipMemcpyAsync(c->d_dir.p, dir.data(), dir.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_yawR.p, yawR.data(), yawR.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    c->rp = *p;
+    c->n_yaw = n_yaw; c->n_elev = p->n_elev; c->window = k;
+    c->have_ray = true;
+    c->max_gt = 0.0; c->min_gt = 0.0;
+    return FS_OK;
+}
+
+int fs_ray_fan_shape(const fs_ctx *c, int32_t *n_yaw, int32_t *n_elev, int32_t *window)
+{
+    if (!c || !c->have_ray) return FS_E_STATE;
+    if (n_yaw) *n_yaw = c->n_yaw;
+    if (n_elev) *n_elev = c->n_elev;
+    if (window) *window = c->window;
+    return FS_OK;
+}
+
+int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int32_t nz,
+                   const double origin_xyz[3], double resolution)
+{
+    if (!c || !cells || !origin_xyz) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
+    const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
+    if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
+    FS_HIP(c, c->d_cells.ensure((size_t)total));
+    FS_HIP(c, hipMemcpyAsync(c->d_cells.p, cells, (size_t)total, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nx = nx; c->ny = ny; c->nz = nz;
+    c->origin[0] = origin_xyz[0]; c->origin[1] = origin_xyz[1]; c->origin[2] = origin_xyz[2];
+    c->res = resolution;
+    c->have_grid = true;
+    c->max_gt = 0.0; c->min_gt = 0.0;
+    return FS_OK;
+}
+
+int fs_set_arrival_limits(fs_ctx *c, double max_gt, double min_gt)
+{
+    if (!c) return FS_E_INVALID;
+    c->max_gt = max_gt; c->min_gt = min_gt;
+    return FS_OK;
+}
+
+int fs_max_arrival(fs_ctx *c, double *max_value, double *max_gt, double *min_gt)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    int rc = check_scoring_state(c, true, false);
+    if (rc) return rc;
+    FsRayArgs a{};
+    fill_ray_args(c, a);
+    // DEP/src/CostCalculator.cpp:140 visitor (260,260,0,255); :142-148 no clamping; start (0,0)
+    a.obst_min = 260; a.obst_max = 260; a.trace_min = 0; a.trace_max = 255;
+    a.clamp = 0;
+    a.min_gt = 0.0;
+    a.footprint_radius = 0.0;
+    const double zcal = (c->nz > 1) ? c->origin[2] + 0.5 * c->nz * c->res : c->origin[2];
+    const double goal[3] = {0.0, 0.0, zcal};
+    FS_HIP(c, c->d_goal.ensure(3));
+    rc = ensure_candidate_scratch(c, 1, false);
+    if (rc) return rc;
+    FS_HIP(c, hipMemcpyAsync(c->d_goal.p, goal, sizeof goal, hipMemcpyHostToDevice, c->stream));
+    a.n = 1; a.goal = c->d_goal.p;
+    a.arrival = c->d_arrival.p; a.argmax = c->d_argmax.p; a.status = c->d_status.p;
+    a.yaw = c->d_yaw.p; a.achievable = c->d_ach.p;
+    {
+        ScopedTimer t(c, 0);
+        FS_HIP(c, fs_launch_raymarch(a, c->stream));
+    }
+    int32_t arrival = 0, status = 0;
+    FS_HIP(c, hipMemcpyAsync(&arrival, c->d_arrival.p, 4, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(&status, c->d_status.p, 4, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    if (status != FS_STATUS_OK) {
+        // :145-148 — returns 0 and leaves the limits unset
+        if (max_value) *max_value = 0.0;
+        if (max_gt) *max_gt = c->max_gt;
+        if (min_gt) *min_gt = c->min_gt;
+        return FS_OK;
+    }
+    c->max_gt = arrival * c->rp.factor_max;           // :186
+    c->min_gt = c->rp.factor_min * c->max_gt;         // :188
+    if (max_value) *max_value = (double)arrival;
+    if (max_gt) *max_gt = c->max_gt;
+    if (min_gt) *min_gt = c->min_gt;
+    return FS_OK;
+}
+
+static int upload_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *fsize,
+                             const uint8_t *black, const uint8_t *achin)
+{
+    FS_HIP(c, c->d_goal.ensure((size_t)n * 3));
+    FS_HIP(c, hipMemcpyAsync(c->d_goal.p, goal_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (fsize) {
+        FS_HIP(c, c->d_fsize.ensure(n));
+        FS_HIP(c, hipMemcpyAsync(c->d_fsize.p, fsize, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    if (black) {
+        FS_HIP(c, c->d_black.ensure(n));
+        FS_HIP(c, hipMemcpyAsync(c->d_black.p, black, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    if (achin) {
+        FS_HIP(c, c->d_achin.ensure(n));
+        FS_HIP(c, hipMemcpyAsync(c->d_achin.p, achin, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    return FS_OK;
+}
+
+int fs_score_arrival(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                     const uint8_t *blacklisted, const uint8_t *achievable_in,
+                     int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
+                     uint8_t *achievable, int32_t *status)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    int rc = check_scoring_state(c, true, false);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!goal_xyz || !arrival || !argmax || !yaw || !achievable || !status)))
+        return fail(c, FS_E_INVALID, "null output or input pointer");
+    if (n == 0) return FS_OK;
+    rc = upload_candidates(c, n, goal_xyz, frontier_size, blacklisted, achievable_in);
+    if (rc) return rc;
+    rc = ensure_candidate_scratch(c, n, false);
+    if (rc) return rc;
+    const size_t per = (size_t)c->n_yaw * c->n_elev;
+    if (ray_counts) FS_HIP(c, c->d_raycounts.ensure((size_t)n * per));
+    FsRayArgs a{};
+    fill_ray_args(c, a);
+    a.n = n; a.goal = c->d_goal.p;
+    a.frontier_size = frontier_size ? c->d_fsize.p : nullptr;
+    a.blacklisted = blacklisted ? c->d_black.p : nullptr;
+    a.achievable_in = achievable_in ? c->d_achin.p : nullptr;
+    a.ray_counts = ray_counts ? c->d_raycounts.p : nullptr;
+    a.arrival = c->d_arrival.p; a.argmax = c->d_argmax.p; a.status = c->d_status.p;
+    a.yaw = c->d_yaw.p; a.achievable = c->d_ach.p;
+    {
+        ScopedTimer t(c, 0);
+        FS_HIP(c, fs_launch_raymarch(a, c->stream));
+    }
+    if (ray_counts) FS_HIP(c, hipMemcpyAsync(ray_counts, c->d_raycounts.p, sizeof(int32_t) * (size_t)n * per, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(arrival, c->d_arrival.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(argmax, c->d_argmax.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(status, c->d_status.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(yaw, c->d_yaw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(achievable, c->d_ach.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    return FS_OK;
+}
+
+// ------------------------------------------------------------------ Fisher information
+
+int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
+{
+    if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    const int32_t mp = std::max<int32_t>(FS_LM_PAD, (m + FS_LM_PAD - 1) / FS_LM_PAD * FS_LM_PAD);
+    // SoA + far-away sentinels in the padding: (1e18)^2 is finite in fp32 and beyond any max_dist^2
+    std::vector<float> x((size_t)mp, 1.0e18f), y((size_t)mp, 1.0e18f), z((size_t)mp, 1.0e18f);
+    for (int32_t i = 0; i < m; ++i) { x[i] = xyz[3 * i]; y[i] = xyz[3 * i + 1]; z[i] = xyz[3 * i + 2]; }
+    FS_HIP(c, c->d_lx.ensure(mp)); FS_HIP(c, c->d_ly.ensure(mp)); FS_HIP(c, c->d_lz.ensure(mp));
+    FS_HIP(c, hipMemcpyAsync(c->d_lx.p, x.data(), sizeof(float) * mp, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_ly.p, y.data(), sizeof(float) * mp, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_lz.p, z.data(), sizeof(float) * mp, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    c->m = m; c->m_padded = mp;
+    // HBM hash tables for the overflow pass: one per pool workgroup, 2x the landmark count
+    int gb = 12;
+    while ((1ll << gb) < 2ll * std::max(m, 1)) ++gb;
+    c->ghash_bits = gb;
+    FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
+    c->have_lm = true;
+    return FS_OK;
+}
+
+int fs_lookup_generate(fs_ctx *c, const float bounds[6])
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    // DEP/src/fisher_information/GenerateLookupMain.cpp:9 — double literals narrowed to the float parameters
+    const float def[6] = {(float)0.0, (float)21.0, (float)(-8.5 * 1.732), (float)(8.5 * 1.732), (float)(-8.5 * 1.732), (float)(8.5 * 1.732)};
+    const float *b = bounds ? bounds : def;
+    generate_records(b[0], b[1], b[2], b[3], b[4], b[5], c->records);
+    return build_dense(c);
+}
+
+int fs_lookup_set_records(fs_ctx *c, const float *records, int64_t n)
+{
+    if (!c || !records || n <= 0) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    c->records.assign(records, records + 4 * n);
+    return build_dense(c);
+}
+
+int fs_lookup_load(fs_ctx *c, const char *path)
+{
+    if (!c || !path) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(c, FS_E_IO, "Cannot load lookup table. Does it exist in the path? (%s)", path);
+    std::vector<float> rec;
+    float r[4];
+    while (std::fread(r, sizeof(float), 4, f) == 4) rec.insert(rec.end(), r, r + 4);   // FisherInfoManager.cpp:247-248
+    std::fclose(f);
+    if (rec.empty()) return fail(c, FS_E_IO, "lookup table file %s holds no complete record", path);
+    c->records.swap(rec);
+    return build_dense(c);
+}
+
+int fs_lookup_save(fs_ctx *c, const char *path)
+{
+    if (!c || !path) return FS_E_INVALID;
+    if (!c->have_table) return fail(c, FS_E_STATE, "no lookup table to save");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(c, FS_E_IO, "Error opening file for writing (%s)", path);
+    const size_t n = c->records.size();
+    const size_t w = std::fwrite(c->records.data(), sizeof(float), n, f);
+    std::fclose(f);
+    return w == n ? FS_OK : fail(c, FS_E_IO, "short write to %s", path);
+}
+
+int fs_lookup_num_records(const fs_ctx *c, int64_t *n)
+{
+    if (!c || !n) return FS_E_INVALID;
+    *n = (int64_t)c->records.size() / 4;
+    return FS_OK;
+}
+
+int fs_lookup_get_records(const fs_ctx *c, float *records)
+{
+    if (!c || !records) return FS_E_INVALID;
+    std::memcpy(records, c->records.data(), c->records.size() * sizeof(float));
+    return FS_OK;
+}
+
+int fs_lookup_query(const fs_ctx *c, const float p[3], float *value)
+{
+    if (!c || !p || !value) return FS_E_INVALID;
+    if (!c->have_table) return FS_E_STATE;
+    float key[3];
+    long j[3];
+    voxel_coordinate(p[0], p[1], p[2], key, j);
+    const long jx = j[0] - c->jx0, jy = j[1] - c->jy0, jz = j[2] - c->jz0;
+    if (jx < 0 || jx >= c->tx || jy < 0 || jy >= c->ty || jz < 0 || jz >= c->tz) *value = std::numeric_limits<float>::quiet_NaN();
+    else *value = c->dense[((size_t)jx * c->ty + jy) * c->tz + jz];
+    return FS_OK;
+}
+
+int fs_set_fim_params(fs_ctx *c, const fs_fim_params *p)
+{
+    if (!c || !p) return FS_E_INVALID;
+    if (!(p->max_dist > 0.0) || !(p->max_angle > 0.0)) return fail(c, FS_E_INVALID, "max_dist and max_angle must be positive");
+    c->fp = *p;
+    return FS_OK;
+}
+
+static int run_fim(fs_ctx *c, FsFimArgs &a)
+{
+    a.info_ref = c->d_info.p; a.trace = c->d_trace.p; a.logdet = c->d_logdet.p;
+    a.n_visible = c->d_nvis.p; a.n_voxels = c->d_nvox.p; a.overflow = c->d_overflow.p;
+    a.sums = c->d_sums.p;
+    {
+        ScopedTimer t(c, 1);
+        FS_HIP(c, fs_launch_fim(a, c->stream));
+    }
+    if (a.hash_bits < 20 && (1 << a.hash_bits) < 2 * c->m) {
+        // the LDS table can fill up only when the cloud has more landmarks than half its slots
+        ScopedTimer t(c, 2);
+        FS_HIP(c, fs_launch_fim_overflow(a, fs_ctx::kPool, c->stream));
+    }
+    FS_HIP(c, fs_launch_fim_finish(a, c->stream));
+    return FS_OK;
+}
+
+int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, float *fim21,
+                 float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    int rc = check_scoring_state(c, false, true);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!pose7 || !info_ref))) return fail(c, FS_E_INVALID, "null pose or output pointer");
+    if (n == 0) return FS_OK;
+    std::vector<float> Rt((size_t)n * 12);
+    for (int32_t i = 0; i < n; ++i) pose_to_rt(pose7 + 7 * (size_t)i, &Rt[12 * (size_t)i]);
+    FS_HIP(c, c->d_Rt.ensure(Rt.size()));
+    FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, Rt.data(), Rt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = ensure_candidate_scratch(c, n, fim21 != nullptr);
+    if (rc) return rc;
+    FsFimArgs a{};
+    fill_fim_args(c, a);
+    a.n = n; a.Rt = c->d_Rt.p;
+    a.fim21 = fim21 ? c->d_fim21.p : nullptr;
+    rc = run_fim(c, a);
+    if (rc) return rc;
+    FS_HIP(c, hipMemcpyAsync(info_ref, c->d_info.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (fim21) FS_HIP(c, hipMemcpyAsync(fim21, c->d_fim21.p, sizeof(float) * 21 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (trace) FS_HIP(c, hipMemcpyAsync(trace, c->d_trace.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (logdet) FS_HIP(c, hipMemcpyAsync(logdet, c->d_logdet.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (n_visible) FS_HIP(c, hipMemcpyAsync(n_visible, c->d_nvis.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (n_voxels) FS_HIP(c, hipMemcpyAsync(n_voxels, c->d_nvox.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    return FS_OK;
+}
+
+// ------------------------------------------------------------------ fused scoring
+
+int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, const int32_t *d_frontier_size,
+                            const uint8_t *d_blacklisted, const uint8_t *d_achievable_in, fs_record *d_records)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    int rc = check_scoring_state(c, true, true);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!d_goal_xyz || !d_records))) return fail(c, FS_E_INVALID, "null device pointer");
+    if (n == 0) return FS_OK;
+    rc = ensure_candidate_scratch(c, n, false);
+    if (rc) return rc;
+    FsRayArgs ra{};
+    fill_ray_args(c, ra);
+    ra.n = n; ra.goal = d_goal_xyz;
+    ra.frontier_size = d_frontier_size; ra.blacklisted = d_blacklisted; ra.achievable_in = d_achievable_in;
+    ra.ray_counts = nullptr;
+    ra.arrival = c->d_arrival.p; ra.argmax = c->d_argmax.p; ra.status = c->d_status.p;
+    ra.yaw = c->d_yaw.p; ra.achievable = c->d_ach.p;
+    {
+        ScopedTimer t(c, 0);
+        FS_HIP(c, fs_launch_raymarch(ra, c->stream));
+    }
+    FsFimArgs fa{};
+    fill_fim_args(c, fa);
+    fa.n = n; fa.Rt = nullptr;
+    fa.goal = d_goal_xyz; fa.argmax = c->d_argmax.p; fa.status = c->d_status.p; fa.yawR = c->d_yawR.p;
+    fa.fim21 = nullptr;
+    rc = run_fim(c, fa);
+    if (rc) return rc;
+    FsPackArgs pa{};
+    pa.n = n;
+    pa.arrival = c->d_arrival.p; pa.argmax = c->d_argmax.p; pa.status = c->d_status.p;
+    pa.yaw = c->d_yaw.p; pa.achievable = c->d_ach.p;
+    pa.info_ref = c->d_info.p; pa.trace = c->d_trace.p; pa.logdet = c->d_logdet.p;
+    pa.n_visible = c->d_nvis.p; pa.n_voxels = c->d_nvox.p;
+    pa.records = d_records;
+    FS_HIP(c, fs_launch_pack(pa, c->stream));
+    return FS_OK;
+}
+
+int fs_score_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                        const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!goal_xyz || !records))) return fail(c, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    int rc = check_scoring_state(c, true, true);
+    if (rc) return rc;
+    rc = upload_candidates(c, n, goal_xyz, frontier_size, blacklisted, achievable_in);
+    if (rc) return rc;
+    FS_HIP(c, c->d_records.ensure(n));
+    rc = fs_score_candidates_dev(c, n, c->d_goal.p, frontier_size ? c->d_fsize.p : nullptr,
+                                 blacklisted ? c->d_black.p : nullptr, achievable_in ? c->d_achin.p : nullptr,
+                                 c->d_records.p);
+    if (rc) return rc;
+    FS_HIP(c, hipMemcpyAsync(records, c->d_records.p, sizeof(fs_record) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    return FS_OK;
+}
+
+// ------------------------------------------------------------------ utility + ranking
+
+int fs_rank_candidates(fs_ctx *c, int32_t n, const fs_record *records, const uint8_t *blacklisted,
+                       const double *path_length, const double *path_heading,
+                       double alpha, double beta, double max_vx, double max_wz,
+                       double *weighted_cost, double *arrival_utility, double *distance_utility,
+                       int32_t *order)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!records || !path_length || !path_heading || !weighted_cost))) return fail(c, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    FS_HIP(c, c->d_records.ensure(n)); FS_HIP(c, c->d_len.ensure(n)); FS_HIP(c, c->d_head.ensure(n));
+    FS_HIP(c, c->d_cost.ensure(n)); FS_HIP(c, c->d_au.ensure(n)); FS_HIP(c, c->d_du.ensure(n));
+    FS_HIP(c, c->d_order.ensure(n)); FS_HIP(c, c->d_err.ensure(1));
+    FS_HIP(c, hipMemcpyAsync(c->d_records.p, records, sizeof(fs_record) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_len.p, path_length, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_head.p, path_heading, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (blacklisted) {
+        FS_HIP(c, c->d_black.ensure(n));
+        FS_HIP(c, hipMemcpyAsync(c->d_black.p, blacklisted, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    {
+        ScopedTimer t(c, 3);
+        FS_HIP(c, fs_launch_rank(n, c->d_records.p, blacklisted ? c->d_black.p : nullptr, c->d_len.p, c->d_head.p,
+                                 alpha, beta, max_vx, max_wz, c->max_gt, c->d_cost.p, c->d_au.p, c->d_du.p,
+                                 c->d_order.p, c->d_err.p, &c->rank_scratch, &c->rank_scratch_bytes, c->stream));
+    }
+    int32_t err = 0;
+    FS_HIP(c, hipMemcpyAsync(&err, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(weighted_cost, c->d_cost.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (arrival_utility) FS_HIP(c, hipMemcpyAsync(arrival_utility, c->d_au.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (distance_utility) FS_HIP(c, hipMemcpyAsync(distance_utility, c->d_du.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (order) FS_HIP(c, hipMemcpyAsync(order, c->d_order.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    if (err) return fail(c, FS_E_RANGE, "utility outside [0,1] (the reference throws: FrontierCostsManager.cpp:148-149,173-174)");
+    return FS_OK;
+}
+
+// ------------------------------------------------------------------ self test
+
+int fs_selftest_fp64(fs_ctx *c, int32_t max_abs, int64_t *mismatches)
+{
+    if (!c || !mismatches || max_abs < 1 || max_abs > 2048) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    const int side = max_abs + 1;
+    const size_t total = (size_t)side * side;
+    DevBuf<double> ds, dd;
+    FS_HIP(c, ds.ensure(total)); FS_HIP(c, dd.ensure(total));
+    FS_HIP(c, fs_launch_selftest(max_abs, ds.p, dd.p, c->stream));
+    std::vector<double> hs(total), hd(total);
+    FS_HIP(c, hipMemcpyAsync(hs.data(), ds.p, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(hd.data(), dd.p, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    ds.release(); dd.release();
+    int64_t bad = 0;
+    for (int dx = 0; dx < side; ++dx)
+        for (int dy = 0; dy < side; ++dy) {
+            const size_t t = (size_t)dx * side + dy;
+            // The reference calls std::hypot (Helpers.cpp:49); glibc's hypot is within 1 ulp but not
+            // always correctly rounded, so the device (and this check) use the correctly rounded sqrt of
+            // the exact integer dx^2+dy^2.  A 1-ulp change of dist cannot flip (unsigned)(scale*abs_da):
+            // tests/test_oracle_raycast.py::test_hypot_vs_sqrt_never_changes_step_count proves it exhaustively.
+            const double dist = std::sqrt((double)((long long)dx * dx + (long long)dy * dy));
+            const double q = (dist == 0.0) ? 1.0 : 40.0 / dist;
+            if (std::memcmp(&dist, &hs[t], 8) != 0) ++bad;
+            if (std::memcmp(&q, &hd[t], 8) != 0) ++bad;
+        }
+    *mismatches = bad;
+    return FS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// fs_internal.h — structures shared by the HIP kernels and the C-ABI host layer (not installed).
+#ifndef FS_INTERNAL_H_
+#define FS_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fitslam_frontier.h"
+
+// ---- ray-march kernel arguments ---------------------------------------------------------------
+struct FsGridDev {
+    const uint8_t *cells;      // [nz][ny][nx]
+    int32_t nx, ny, nz;
+    double ox, oy, oz;         // origin
+    double res;
+};
+
+struct FsRayArgs {
+    FsGridDev grid;
+    // fan geometry, precomputed on the host in double with libm (ray directions are
+    // candidate-independent; device cos/sin could differ from libm in the last ulp and flip a
+    // truncation at a cell boundary):  dir[(e*n_yaw + i)*3 + {0,1,2}] = D*cos(phi_e)*cos(theta_i), ... , D*sin(phi_e)
+    const double *dir;
+    int32_t n_yaw, n_elev, window;
+    uint32_t max_length;       // (unsigned)(max_camera_depth / resolution), CostCalculator.cpp:28
+    int32_t obst_min, obst_max, trace_min, trace_max;
+    int32_t clamp;             // CostCalculator.cpp:47-48 (1) or setMaxArrivalInformation (0)
+    double lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // folded clamp bounds: max(poly_min, origin), min(poly_max, origin + sizeInMeters)
+    double footprint_radius;   // ceil(robot_radius / resolution)
+    double delta_theta, half_fov;
+    double min_gt;             // min_arrival_info_gt_
+    // candidates
+    int32_t n;
+    const double *goal;        // [n][3]
+    const int32_t *frontier_size;   // or nullptr
+    const uint8_t *blacklisted;     // or nullptr
+    const uint8_t *achievable_in;   // or nullptr
+    // outputs (device)
+    int32_t *ray_counts;       // [n][n_elev][n_yaw] or nullptr
+    int32_t *arrival, *argmax, *status;
+    double *yaw;
+    uint8_t *achievable;
+};
+
+// ---- FIM kernel arguments ---------------------------------------------------------------------
+struct FsFimArgs {
+    // landmarks, SoA, padded to a multiple of FS_LM_PAD with far-away sentinels
+    const float *lx, *ly, *lz;
+    int32_t m_padded;
+    // dense lookup table indexed by the integer voxel lattice
+    const float *table;        // [tx][ty][tz], NaN = absent
+    int32_t jx0, jy0, jz0;     // lattice index of table[0][0][0]
+    int32_t tx, ty, tz;
+    double inv_step;           // 1 / (double)0.3f  (FisherInfoManager.hpp:119)
+    const float *factor;       // crowding factor by rank, [FS_FACTOR_N]; rank >= FS_FACTOR_N -> 0
+    // visibility
+    float maxd2;               // (float)(max_dist^2)
+    float cos2;                // c*c, c = (float)cos(max_angle)
+    int32_t cone_mode;         // 0 disabled, 1 c >= 0, 2 c < 0
+    // poses: either explicit Rt[n][12] (R row-major 9 + t 3) or from the arrival outputs
+    int32_t n;
+    const float *Rt;           // explicit poses or nullptr
+    const double *goal;        // [n][3]       (pose-from-arrival mode)
+    const int32_t *argmax;     // [n]
+    const int32_t *status;     // [n] or nullptr: status != 0 -> zero FI
+    const float *yawR;         // [n_windows][9] rotation per argmax index
+    // outputs (device)
+    float *info_ref, *trace, *logdet, *fim21;   // fim21 may be nullptr
+    int32_t *n_visible, *n_voxels;
+    double *sums;              // [n][18] reduced per-candidate sums (info, 15 FIM block sums, n_visible, n_voxels)
+    uint32_t *overflow;        // [n] set to 1 when the LDS table filled up (second pass needed)
+    // hash table
+    int32_t hash_bits;
+    uint32_t *gtable;          // global-memory tables for the overflow pass: [pool][1 << ghash_bits]
+    int32_t ghash_bits;
+};
+
+#define FS_LM_PAD      4096     // landmark arrays are padded to a multiple of this (1024 threads x 4)
+#define FS_FACTOR_N    512      // exp(1 - k^0.8) underflows to 0.0f for k > ~340
+#define FS_SLOT_CNT_BITS 11     // slot = (key+1) << 11 | count
+#define FS_SLOT_CNT_MASK ((1u << FS_SLOT_CNT_BITS) - 1u)
+#define FS_SLOT_CNT_SAT  1024u  // counts beyond this contribute exactly 0.0f anyway
+#define FS_MAX_TABLE_CELLS ((1u << (32 - FS_SLOT_CNT_BITS)) - 2u)
+
+// record assembly
+struct FsPackArgs {
+    int32_t n;
+    const int32_t *arrival, *argmax, *status;
+    const double *yaw;
+    const uint8_t *achievable;
+    const float *info_ref, *trace, *logdet;
+    const int32_t *n_visible, *n_voxels;
+    fs_record *records;
+};
+
+// launchers (defined in the .hip files)
+hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s);
+hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s);
+hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
+hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);
+hipError_t fs_launch_pack(const FsPackArgs &a, hipStream_t s);
+hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hipStream_t s);
+size_t fs_fim_lds_bytes(int hash_bits);
+
+#endif

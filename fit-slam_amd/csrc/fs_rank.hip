@@ -1,0 +1,139 @@
+// fs_rank.hip — U1 utility, weighted cost and ranking of the scored candidates on the GPU.
+//
+// Replaces the tail of FrontierCostsManager::assignCosts (DEP/src/FrontierCostsManager.cpp:118,126-205):
+// running min/max of path length and arrival information over the achievable candidates
+// (recomputeNormalizationFactors, DEP/src/CostCalculator.cpp:512-520), then per candidate
+//   u = alpha * (arrival / max_arrival_gt) + (1 - alpha) * (1 - (len/vmax + heading/wmax) / (maxlen/vmax + pi/wmax)),
+//   cost = 1 / (beta * u).
+// All arithmetic is fp64 with the reference's operation order (basic IEEE ops only), so costs match
+// the CPU bit for bit.  Ranking = stable ascending sort by cost (rocPRIM radix sort on the
+// order-preserving integer image of the double).
+#include "fs_internal.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace {
+
+#define FS_DBL_MAX 1.7976931348623157e308
+
+struct RankNorm {
+    double min_dist, max_dist, min_info;
+};
+
+__device__ __forceinline__ double wave_min(double x)
+{
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(x, d); x = (o < x) ? o : x; }
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x)
+{
+    for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(x, d); x = (x < o) ? o : x; }
+    return x;
+}
+
+// reset() + recomputeNormalizationFactors over the list (CostCalculator.hpp:110-116, CostCalculator.cpp:512-520)
+__global__ __launch_bounds__(1024)
+void fs_rank_norm_kernel(int32_t n, const fs_record *rec, const uint8_t *black, const double *len,
+                         RankNorm *out, int32_t *err)
+{
+    __shared__ double s_min_d[16], s_max_d[16], s_min_i[16];
+    double min_d = FS_DBL_MAX, max_d = -1.0, min_i = FS_DBL_MAX;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (black && black[i]) continue;
+        if (!(rec[i].flags & FS_FLAG_ACHIEVABLE)) continue;
+        const double l = len[i], a = (double)rec[i].arrival;
+        min_d = (l < min_d) ? l : min_d;
+        max_d = (max_d < l) ? l : max_d;
+        min_i = (a < min_i) ? a : min_i;
+    }
+    min_d = wave_min(min_d); max_d = wave_max(max_d); min_i = wave_min(min_i);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s_min_d[wave] = min_d; s_max_d[wave] = max_d; s_min_i[wave] = min_i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            min_d = (s_min_d[w] < min_d) ? s_min_d[w] : min_d;
+            max_d = (max_d < s_max_d[w]) ? s_max_d[w] : max_d;
+            min_i = (s_min_i[w] < min_i) ? s_min_i[w] : min_i;
+        }
+        out->min_dist = min_d; out->max_dist = max_d; out->min_info = min_i;
+        *err = 0;
+    }
+}
+
+__device__ __forceinline__ uint64_t sortable(double v)
+{
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ void fs_rank_cost_kernel(int32_t n, const fs_record *rec, const uint8_t *black, const double *len,
+                                    const double *head, const RankNorm *norm, double alpha, double beta,
+                                    double max_vx, double max_wz, double max_gt,
+                                    double *cost, double *au_out, double *du_out,
+                                    uint64_t *keys, int32_t *vals, int32_t *err)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double PI = 3.14159265358979323846;
+    double c, au, pu;
+    const bool bl = black && black[i];
+    if (bl || !(rec[i].flags & FS_FLAG_ACHIEVABLE)) {
+        // FrontierCostsManager.cpp:84 (blacklisted) / :129-135 (not achievable)
+        c = FS_DBL_MAX; au = -69.8; pu = -1.8;
+    } else {
+        const double max_d = norm->max_dist, min_d = norm->min_dist, min_i = norm->min_info;
+        if ((double)(max_gt - min_i) == 0.0) au = 0.0;                                  // :139-140
+        else au = (double)rec[i].arrival / (double)max_gt;                                // :145-146
+        if ((double)((max_d / max_vx + PI / max_wz) - (min_d / max_vx + 0.0 / max_wz) == 0.0)) pu = 1.0;   // :152-153
+        else pu = (double)(len[i] / max_vx + head[i] / max_wz) / (double)(max_d / max_vx + PI / max_wz);     // :158-159
+        pu = 1.0 - pu;                                                                    // :160
+        if (au > 1.0 || au < 0.0 || pu > 1.0 || pu < 0.0) atomicOr(err, 1);              // :148-149,173-174
+        double utility = (alpha * au) + ((1.0 - alpha) * pu);                             // :176-177
+        if (utility == 0.0) utility = 1e-16;                                              // :178-182
+        c = 1 / (beta * utility);                                                         // :198
+    }
+    cost[i] = c; au_out[i] = au; du_out[i] = pu;
+    keys[i] = sortable(c);
+    vals[i] = i;
+}
+
+}  // namespace
+
+hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *d_black,
+                          const double *d_len, const double *d_head, double alpha, double beta,
+                          double max_vx, double max_wz, double max_gt, double *d_cost, double *d_au,
+                          double *d_du, int32_t *d_order, int32_t *d_err, void **scratch, size_t *scratch_bytes,
+                          hipStream_t s)
+{
+    size_t temp_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                                             (int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, 0, 64, s);
+    if (e != hipSuccess) return e;
+    const size_t off_keys_in = 256;
+    const size_t off_keys_out = off_keys_in + ((sizeof(uint64_t) * (size_t)n + 255) & ~(size_t)255);
+    const size_t off_vals_in = off_keys_out + ((sizeof(uint64_t) * (size_t)n + 255) & ~(size_t)255);
+    const size_t off_temp = off_vals_in + ((sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255);
+    const size_t need = off_temp + temp_bytes + 256;
+    if (need > *scratch_bytes) {
+        if (*scratch) (void)hipFree(*scratch);
+        *scratch = nullptr; *scratch_bytes = 0;
+        e = hipMalloc(scratch, need);
+        if (e != hipSuccess) return e;
+        *scratch_bytes = need;
+    }
+    char *base = static_cast<char *>(*scratch);
+    RankNorm *norm = reinterpret_cast<RankNorm *>(base);
+    uint64_t *keys_in = reinterpret_cast<uint64_t *>(base + off_keys_in);
+    uint64_t *keys_out = reinterpret_cast<uint64_t *>(base + off_keys_out);
+    int32_t *vals_in = reinterpret_cast<int32_t *>(base + off_vals_in);
+    void *temp = base + off_temp;
+
+    hipLaunchKernelGGL(fs_rank_norm_kernel, dim3(1), dim3(1024), 0, s, n, d_records, d_black, d_len, norm, d_err);
+    hipLaunchKernelGGL(fs_rank_cost_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_black, d_len,
+                       d_head, norm, alpha, beta, max_vx, max_wz, max_gt, d_cost, d_au, d_du, keys_in, vals_in, d_err);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, d_order, (size_t)n, 0, 64, s);
+}

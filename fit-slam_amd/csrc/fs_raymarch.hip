@@ -1,0 +1,278 @@
+// fs_raymarch.hip — arrival-information kernel for gfx950 (CDNA4).
+//
+// Replaces the scalar loops of FrontierCostCalculator::setArrivalInformationForFrontier
+// (DEP/src/CostCalculator.cpp:23-121) and its callees getTracedCells / bresenham2D /
+// RayTracedCells::operator() / isRobotFootprintInLethal (DEP/src/Helpers.cpp:7-96,135-155,
+// DEP/include/.../Helpers.hpp:50-77) for a whole frontier list at once.
+//
+// Mapping: one 64-lane wavefront per candidate, rays strided over the lanes (ray r = lane + 64*j),
+// four candidates per 256-thread workgroup.  The grid and the fan-direction table were staged to HBM
+// once (fs_upload_grid / fs_set_ray_params).  Per ray: the end point, the clamp, both worldToMap
+// truncations, the step count `(unsigned)(scale*abs_da)` are evaluated in fp64 with the exact
+// operation order of the reference (basic IEEE ops only: +, -, /, *, sqrt of an exact integer), so
+// every integer cell index matches the CPU bit for bit; then an integer Bresenham walk reads one
+// byte per step.  Per-yaw sums live in LDS; the FOV window maximum and its first argmax are a
+// wave-shuffle reduction.  This is HBM/L2-bound byte gather: no MFMA.
+#include "fs_internal.h"
+
+#define FS_RAY_WAVES 4          // candidates per workgroup
+#define FS_RAY_UNROLL 4         // speculative cell loads in flight per lane
+
+namespace {
+
+__device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }   // std::min(a,b)
+__device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }   // std::max(a,b)
+
+// nav2_costmap_2d::Costmap2D::worldToMap with a z axis. Quotients >= 2^32 are off-map.
+__device__ __forceinline__ bool world_to_map(const FsGridDev &g, double wx, double wy, double wz,
+                                             uint32_t &mx, uint32_t &my, uint32_t &mz)
+{
+    if (wx < g.ox || wy < g.oy || wz < g.oz) return false;
+    const double qx = (wx - g.ox) / g.res;
+    const double qy = (wy - g.oy) / g.res;
+    const double qz = (wz - g.oz) / g.res;
+    if (!(qx < 4294967296.0) || !(qy < 4294967296.0) || !(qz < 4294967296.0)) return false;
+    mx = (uint32_t)qx;
+    my = (uint32_t)qy;
+    mz = (uint32_t)qz;
+    return mx < (uint32_t)g.nx && my < (uint32_t)g.ny && mz < (uint32_t)g.nz;
+}
+
+__device__ __forceinline__ int sign_ref(int x) { return x > 0 ? 1 : -1; }   // Helpers.hpp:113-116
+
+struct RayWalk {
+    uint32_t offset;
+    uint32_t abs_da, abs_db, abs_dc;
+    int err_b, err_c;
+    int off_a, off_b, off_c;
+    uint32_t end;            // min(max_length_steps, abs_da): loop visits, one more after the loop
+};
+
+__device__ __forceinline__ void walk_step(RayWalk &w)
+{
+    // bresenham2D body, DEP/src/Helpers.cpp:21-27 (+ second minor axis)
+    w.offset += (uint32_t)w.off_a;
+    w.err_b += (int)w.abs_db;
+    if ((uint32_t)w.err_b >= w.abs_da) { w.offset += (uint32_t)w.off_b; w.err_b -= (int)w.abs_da; }
+    w.err_c += (int)w.abs_dc;
+    if ((uint32_t)w.err_c >= w.abs_da) { w.offset += (uint32_t)w.off_c; w.err_c -= (int)w.abs_da; }
+}
+
+// getTracedCells set-up, DEP/src/Helpers.cpp:32-94.
+__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, double sx, double sy, double sz,
+                                          double wx, double wy, double wz, RayWalk &w)
+{
+    const FsGridDev &g = a.grid;
+    uint32_t x1, y1, z1, x0, y0, z0;
+    if (!world_to_map(g, wx, wy, wz, x1, y1, z1) || !world_to_map(g, sx, sy, sz, x0, y0, z0)) return false;
+    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
+    const long long d2 = (long long)dx * dx + (long long)dy * dy + (long long)dz * dz;
+    const double dist = sqrt((double)d2);          // == std::hypot(dx,dy) when dz == 0 (both correctly rounded)
+    const uint32_t nx = (uint32_t)g.nx, ny = (uint32_t)g.ny;
+    w.offset = (z0 * ny + y0) * nx + x0;
+    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
+    const int odx = sign_ref(dx), ody = sign_ref(dy) * (int)nx, odz = sign_ref(dz) * (int)(nx * ny);
+    const double q = (double)a.max_length / dist;
+    const double scale = (dist == 0.0) ? 1.0 : ((q < 1.0) ? q : 1.0);       // std::min(1.0, max_length / dist)
+    if (adx >= ady && adx >= adz) {
+        w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
+    } else if (ady >= adz) {
+        w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz;
+    } else {
+        w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody;
+    }
+    w.err_b = w.err_c = (int)(w.abs_da / 2);
+    const uint32_t max_steps = (uint32_t)(scale * (double)w.abs_da);
+    w.end = max_steps < w.abs_da ? max_steps : w.abs_da;
+    return true;
+}
+
+// RayTracedCells over the walk: number of cells in [trace_min,trace_max] seen before the first
+// cell in [obst_min,obst_max]  (= cells_.size(), DEP/src/CostCalculator.cpp:57-58).
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, RayWalk w)
+{
+    const uint8_t *__restrict__ cells = a.grid.cells;
+    const uint32_t total = (uint32_t)a.grid.nx * (uint32_t)a.grid.ny * (uint32_t)a.grid.nz;
+    const int omin = a.obst_min, omax = a.obst_max, tmin = a.trace_min, tmax = a.trace_max;
+    int count = 0;
+    uint32_t visits = w.end + 1;          // loop visits + the one after the loop (Helpers.cpp:29)
+    while (visits > 0) {
+        // issue up to FS_RAY_UNROLL independent byte loads, then classify them in order; loads past an
+        // obstacle are speculative but always inside the start/end bounding box, hence in the grid
+        int c[FS_RAY_UNROLL];
+        const uint32_t nb = visits < FS_RAY_UNROLL ? visits : FS_RAY_UNROLL;
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            c[u] = -1;
+            if ((uint32_t)u < nb) {
+                c[u] = (w.offset < total) ? (int)cells[w.offset] : 256;   // 256: never traced, never an obstacle
+                walk_step(w);
+            }
+        }
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            if ((uint32_t)u < nb && !hit) {
+                if (c[u] <= tmax && c[u] >= tmin) ++count;          // Helpers.hpp:64-67 (tested before hit is set)
+                if (c[u] >= omin && c[u] <= omax) hit = true;       // Helpers.hpp:68-71
+            }
+        }
+        if (hit) break;                    // nothing is pushed after the first obstacle
+        visits -= nb;
+    }
+    return count;
+}
+
+__global__ __launch_bounds__(FS_RAY_WAVES * 64)
+void fs_raymarch_kernel(const FsRayArgs a)
+{
+    extern __shared__ int fs_ray_lds[];          // [FS_RAY_WAVES][n_yaw] per-yaw sums over the elevation rings
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * FS_RAY_WAVES + wave;
+    const bool active = c < a.n;
+    int *ysum = fs_ray_lds + wave * a.n_yaw;
+    const int n_rays = a.n_yaw * a.n_elev;
+
+    for (int i = lane; i < a.n_yaw; i += 64) ysum[i] = 0;
+    __syncthreads();
+
+    bool black = false;
+    double sx = 0, sy = 0, sz = 0;
+    if (active) {
+        black = a.blacklisted && a.blacklisted[c];
+        sx = a.goal[3 * c]; sy = a.goal[3 * c + 1]; sz = a.goal[3 * c + 2];
+    }
+    bool fail = false;
+    if (active && !black) {
+        for (int r = lane; r < n_rays; r += 64) {
+            const int i = r % a.n_yaw;
+            // DEP/src/CostCalculator.cpp:42-43: wx = sx + (MAX_CAMERA_DEPTH * cos(theta))
+            double wx = sx + a.dir[3 * r];
+            double wy = sy + a.dir[3 * r + 1];
+            double wz = sz + a.dir[3 * r + 2];
+            if (a.clamp) {                                  // :47-48
+                wx = std_max(a.lo_x, std_min(a.hi_x, wx));
+                wy = std_max(a.lo_y, std_min(a.hi_y, wy));
+                wz = std_max(a.lo_z, std_min(a.hi_z, wz));
+            }
+            RayWalk w;
+            int count = 0;
+            if (ray_setup(a, sx, sy, sz, wx, wy, wz, w)) count = ray_march(a, w);
+            else fail = true;
+            if (count) atomicAdd(&ysum[i], count);
+            if (a.ray_counts) a.ray_counts[(size_t)c * n_rays + r] = count;
+        }
+    }
+    const bool any_fail = __any(fail);           // :50-55 — the first failing ray aborts the candidate
+    __syncthreads();
+    if (!active) return;
+
+    uint8_t ach = a.achievable_in ? a.achievable_in[c] : (uint8_t)1;
+    if (black || any_fail) {
+        if (a.ray_counts)
+            for (int r = lane; r < n_rays; r += 64) a.ray_counts[(size_t)c * n_rays + r] = 0;
+        if (lane == 0) {
+            a.arrival[c] = 0; a.argmax[c] = 0; a.yaw[c] = 0.0; a.achievable[c] = ach;
+            a.status[c] = black ? FS_STATUS_BLACKLISTED : FS_STATUS_OFF_MAP;
+        }
+        return;
+    }
+
+    // footprint disc, DEP/src/Helpers.cpp:135-155 in the candidate's z slice; off-grid cells are not lethal
+    uint32_t sxm = 0, sym = 0, szm = 0;
+    world_to_map(a.grid, sx, sy, sz, sxm, sym, szm);
+    const int ri = (int)a.footprint_radius;
+    const int side = 2 * ri + 1;
+    bool lethal = false;
+    for (int t = lane; t < side * side; t += 64) {
+        const int dx = t / side - ri, dy = t % side - ri;
+        if ((double)(dx * dx + dy * dy) <= a.footprint_radius * a.footprint_radius) {
+            const uint32_t x = sxm + (uint32_t)dx, y = sym + (uint32_t)dy;
+            if (x < (uint32_t)a.grid.nx && y < (uint32_t)a.grid.ny) {
+                if (a.grid.cells[((size_t)szm * a.grid.ny + y) * a.grid.nx + x] == 254) lethal = true;
+            }
+        }
+    }
+    lethal = __any(lethal);
+    const int fsize = a.frontier_size ? a.frontier_size[c] : 0;
+    if (lethal && (double)fsize < 10.0) ach = 0;           // CostCalculator.cpp:77-82
+
+    // FOV window, no wrap-around, first maximum (CostCalculator.cpp:87-107)
+    const int k = a.window;
+    int best = -1, best_i = 0x7fffffff;
+    for (int i = lane; i <= a.n_yaw - k; i += 64) {
+        int s = 0;
+        for (int j = 0; j < k; ++j) s += ysum[i + j];
+        if (s > best) { best = s; best_i = i; }            // ascending i per lane: strict > keeps the first
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int ob = __shfl_xor(best, d), oi = __shfl_xor(best_i, d);
+        if (ob > best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    if (lane == 0) {
+        a.arrival[c] = best;                                // :112
+        if ((double)best < a.min_gt) ach = 0;              // :114-118
+        a.argmax[c] = best_i;
+        a.yaw[c] = ((double)best_i * a.delta_theta) + a.half_fov;   // :119, half_fov = CAMERA_FOV / 2
+        a.achievable[c] = ach;
+        a.status[c] = FS_STATUS_OK;
+    }
+}
+
+__global__ void fs_selftest_kernel(int32_t max_abs, double *out_sqrt, double *out_div)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int side = max_abs + 1;
+    if (t >= side * side) return;
+    const int dx = t / side, dy = t % side;
+    const long long d2 = (long long)dx * dx + (long long)dy * dy;
+    const double dist = sqrt((double)d2);
+    out_sqrt[t] = dist;
+    out_div[t] = (dist == 0.0) ? 1.0 : 40.0 / dist;
+}
+
+__global__ void fs_pack_kernel(const FsPackArgs p)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    fs_record r;
+    r.arrival = p.arrival[i];
+    r.argmax = p.argmax[i];
+    r.yaw = (float)p.yaw[i];
+    r.info_ref = p.info_ref ? p.info_ref[i] : 0.0f;
+    r.trace = p.trace ? p.trace[i] : 0.0f;
+    r.logdet = p.logdet ? p.logdet[i] : 0.0f;
+    r.n_visible = p.n_visible ? p.n_visible[i] : 0;
+    const uint32_t nv = p.n_voxels ? (uint32_t)p.n_voxels[i] : 0u;
+    r.flags = (p.achievable[i] ? FS_FLAG_ACHIEVABLE : 0u) | (((uint32_t)p.status[i] & 0xffu) << 8) |
+              ((nv > 65535u ? 65535u : nv) << 16);
+    p.records[i] = r;
+}
+
+}  // namespace
+
+hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
+{
+    if (a.n <= 0) return hipSuccess;
+    const int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
+    const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
+    hipLaunchKernelGGL(fs_raymarch_kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t fs_launch_pack(const FsPackArgs &a, hipStream_t s)
+{
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fs_pack_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hipStream_t s)
+{
+    const int side = max_abs + 1;
+    const int total = side * side;
+    hipLaunchKernelGGL(fs_selftest_kernel, dim3((total + 255) / 256), dim3(256), 0, s, max_abs, d_sqrt, d_div);
+    return hipGetLastError();
+}

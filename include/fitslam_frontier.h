@@ -1,0 +1,222 @@
+/*
+ * fitslam_frontier.h — C ABI of the MI355X-native frontier-scoring path.
+ *
+ * This is the drop-in boundary for ONE hot path of suchetanrs/FIT-SLAM: per-candidate arrival
+ * information (ray fan through the occupancy grid, unknown-cell counts, FOV window max, best yaw)
+ * and landmark Fisher information (voxel-lookup scalar with crowding discount + 6x6 FIM).
+ * Plain pointers and sizes only; no C++ / torch / ROS types.  Every entry point cites the reference
+ * interface it replaces.  Abbreviations (under the FIT-SLAM tree):
+ *   DEP/ = dev_ws/src/DEPRECATED/frontier_exploration/frontier_exploration/
+ *   FIP/ = dev_ws/src/fit-slam2/fisher_information_plugins/
+ *
+ * Conventions
+ *   - every function returns FS_OK (0) or a negative FS_E_* code and never throws; the message of
+ *     the last failure on a context is available from fs_last_error().
+ *   - a context is single-caller (externally synchronised), owns one HIP stream (or borrows the
+ *     one passed at creation) and owns device copies of grid, landmarks and lookup table.
+ *     Host buffers stay caller-owned; nothing is allocated across the ABI.
+ *   - grid layout [nz][ny][nx] uint8, index = (z*ny + y)*nx + x; nz == 1 is the reference's
+ *     nav2_costmap_2d::Costmap2D (cost constants: 255 unknown, 254 lethal, 253 inscribed, 0 free).
+ *   - there is NO CPU fallback: if the HIP runtime or a gfx950 device is missing, fs_ctx_create
+ *     fails with FS_E_NO_DEVICE.
+ */
+#ifndef FITSLAM_FRONTIER_H_
+#define FITSLAM_FRONTIER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_ABI_VERSION 1
+
+/* return codes */
+#define FS_OK            0
+#define FS_E_INVALID    -1   /* bad argument / parameters (e.g. fewer rays than the FOV window) */
+#define FS_E_NO_DEVICE  -2   /* HIP runtime or device unavailable — no CPU fallback exists */
+#define FS_E_HIP        -3   /* a HIP call failed */
+#define FS_E_STATE      -4   /* call order: grid / landmarks / table / params not set yet */
+#define FS_E_IO         -5   /* lookup-table file could not be read or written */
+#define FS_E_RANGE      -6   /* utility outside [0,1] (the reference throws, FrontierCostsManager.cpp:148-149,173-174) */
+
+/* per-candidate status (records.flags bits 8..15, status[] of fs_score_arrival) */
+#define FS_STATUS_OK          0
+#define FS_STATUS_OFF_MAP     1   /* a worldToMap failed: arrival 0, yaw 0 (DEP/src/CostCalculator.cpp:50-55) */
+#define FS_STATUS_BLACKLISTED 2   /* DEP/src/FrontierCostsManager.cpp:77-86 */
+
+#define FS_MAX_ELEV 16
+
+typedef struct fs_ctx fs_ctx;
+
+/* Replaces FrontierCostCalculator's constructor parameters (DEP/src/CostCalculator.cpp:5-21:
+ * costCalculator/max_camera_depth, delta_theta, camera_fov, Costmap2DROS::getRobotRadius()),
+ * the RayTracedCells ranges of DEP/src/CostCalculator.cpp:40, the limits factors of :186-188
+ * (a parameter in fit-slam2: fit_slam2/params/active_slam_exploration_params.yaml:17) and
+ * CostAssigner's polygon bbox (DEP/src/CostAssigner.cpp:148-165). */
+typedef struct {
+    double max_camera_depth;     /* 2.0  */
+    double delta_theta;          /* 0.10 */
+    double camera_fov;           /* 1.04 */
+    double robot_radius;         /* 0.60 */
+    int32_t n_rays;              /* 0: the reference loop `theta <= 2*pi` (63 rays at 0.10); >0: exactly n yaw rays */
+    int32_t n_elev;              /* elevation rings of the 3-D extension; 1 with elev[0] == 0 is the reference */
+    double elev[FS_MAX_ELEV];    /* radians */
+    int32_t obst_min, obst_max;  /* 240, 254 */
+    int32_t trace_min, trace_max;/* 255, 255 */
+    double factor_max;           /* 1.2  */
+    double factor_min;           /* 0.70 */
+    double polygon[4];           /* minx, miny, maxx, maxy */
+} fs_ray_params;
+
+/* Replaces the GetLandmarksInView request fields (FIP/src/fisher_information/FisherInfoManager.cpp:60-65)
+ * by an explicit visibility predicate (DESIGN.md "Visibility"). */
+typedef struct {
+    double max_dist;             /* 14.0 */
+    double max_angle;            /* 1.0 rad from the camera +x axis; >= pi disables the cone */
+} fs_fim_params;
+
+/* Fixed-size per-candidate result record (the unit of the multi-GPU all-gather). 32 bytes. */
+typedef struct {
+    int32_t arrival;             /* Frontier::setArrivalInformation (DEP/src/CostCalculator.cpp:112) */
+    int32_t argmax;              /* maxIndex of the FOV window (:98-107) */
+    float   yaw;                 /* goal orientation, maxIndex*delta_theta + fov/2 (:119) */
+    float   info_ref;            /* isPoseSafe's `information` (FIP/src/.../FisherInfoManager.cpp:100) */
+    float   trace;               /* trace of the unit-weight 6x6 FIM over the visible landmarks */
+    float   logdet;              /* log det of that FIM (D-optimality); -inf if singular */
+    int32_t n_visible;           /* landmarks passing the visibility predicate */
+    uint32_t flags;              /* bit0 achievable; bits 8..15 status; bits 16..31 min(n_voxels, 65535) */
+} fs_record;
+
+#define FS_FLAG_ACHIEVABLE 1u
+#define FS_RECORD_STATUS(flags)   (((flags) >> 8) & 0xffu)
+#define FS_RECORD_NVOXELS(flags)  (((flags) >> 16) & 0xffffu)
+
+/* ---------------------------------------------------------------- context */
+
+/* device_id: HIP device ordinal.  stream: a hipStream_t to borrow (e.g. the caller's current
+ * stream) or NULL to create one owned by the context. */
+int  fs_ctx_create(int device_id, void *stream, fs_ctx **out);
+void fs_ctx_destroy(fs_ctx *ctx);
+const char *fs_last_error(const fs_ctx *ctx);
+int  fs_abi_version(void);
+int  fs_synchronize(fs_ctx *ctx);
+
+/* Per-kernel device time.  With timing enabled every kernel launch is bracketed by hipEvents on
+ * the context's stream; fs_kernel_time returns and resets the accumulated (ms, launches) of
+ * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM overflow pass, 3 utility/rank. */
+int  fs_enable_kernel_timing(fs_ctx *ctx, int enable);
+int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
+
+/* ---------------------------------------------------------------- arrival information (ray-cast) */
+
+/* Replaces FrontierCostCalculator::FrontierCostCalculator (DEP/src/CostCalculator.cpp:5-21). */
+int fs_set_ray_params(fs_ctx *ctx, const fs_ray_params *p);
+/* number of yaw rays / FOV window the parameters produce (DEP/src/CostCalculator.cpp:36,87) */
+int fs_ray_fan_shape(const fs_ctx *ctx, int32_t *n_yaw, int32_t *n_elev, int32_t *window);
+
+/* Replaces the raw `nav2_costmap_2d::Costmap2D *exploration_costmap_` the scorer holds
+ * (DEP/src/CostCalculator.cpp:10).  Copies the grid to HBM — the snapshot point; call it under the
+ * costmap mutex.  Invalidates cached arrival limits. */
+int fs_upload_grid(fs_ctx *ctx, const uint8_t *cells, int32_t nx, int32_t ny, int32_t nz,
+                   const double origin_xyz[3], double resolution);
+
+/* Replaces double FrontierCostCalculator::setMaxArrivalInformation() (DEP/include/.../CostCalculator.hpp:58,
+ * DEP/src/CostCalculator.cpp:123-191): geometric maximum of the FOV window on an obstacle-free fan from
+ * world (0,0).  max_value = the window maximum (0 if (0,0) is off-map: limits stay unset, as the
+ * reference); caches max_gt = factor_max*max_value, min_gt = factor_min*max_gt in the context. */
+int fs_max_arrival(fs_ctx *ctx, double *max_value, double *max_gt, double *min_gt);
+/* override the cached limits (e.g. restored from a running node) */
+int fs_set_arrival_limits(fs_ctx *ctx, double max_gt, double min_gt);
+
+/* Replaces void FrontierCostCalculator::setArrivalInformationForFrontier(FrontierPtr&, std::vector<double>&)
+ * (DEP/include/.../CostCalculator.hpp:56, DEP/src/CostCalculator.cpp:23-121) applied to the whole
+ * frontier list of FrontierCostsManager::assignCosts (DEP/src/FrontierCostsManager.cpp:74-119),
+ * including its blacklist branch (:77-86).  Order-preserving.
+ *   goal_xyz      [n][3] Frontier::getGoalPoint() (z: origin_z for 2-D grids)
+ *   frontier_size [n]    Frontier::getSize() or NULL (0)
+ *   blacklisted   [n]    or NULL (none)
+ *   achievable_in [n]    Frontier::isAchievable() before the call, or NULL (true)
+ *   ray_counts    [n][n_elev][n_yaw] information_along_ray, or NULL
+ *   arrival, argmax [n]; yaw [n] (theta_s_star); achievable [n]; status [n] */
+int fs_score_arrival(fs_ctx *ctx, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                     const uint8_t *blacklisted, const uint8_t *achievable_in,
+                     int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
+                     uint8_t *achievable, int32_t *status);
+
+/* ---------------------------------------------------------------- Fisher information */
+
+/* Replaces the per-query service response `map_points` (FIP/src/.../FisherInfoManager.cpp:60-88)
+ * by the whole landmark cloud staged once: xyz [m][3] float32, world frame. */
+int fs_upload_landmarks(fs_ctx *ctx, const float *xyz, int32_t m);
+
+/* Replaces generateLookupTable(minX,maxX,minY,maxY,minZ,maxZ) (FIP/include/.../FisherInfoManager.hpp:94,
+ * FIP/src/.../FisherInfoManager.cpp:117-229).  bounds == NULL uses gen_fi_lookup's arguments
+ * (DEP/src/fisher_information/GenerateLookupMain.cpp:9). */
+int fs_lookup_generate(fs_ctx *ctx, const float bounds[6]);
+/* Replaces loadLookupTable() (FisherInfoManager.hpp:96, FisherInfoManager.cpp:231-262): raw
+ * {float key[3]; float value} records, host-endian, no header.  Missing file -> FS_E_IO (the reference throws). */
+int fs_lookup_load(fs_ctx *ctx, const char *path);
+int fs_lookup_save(fs_ctx *ctx, const char *path);        /* byte-compatible with the reference's .dat */
+int fs_lookup_set_records(fs_ctx *ctx, const float *records /* [n][4] */, int64_t n);
+int fs_lookup_num_records(const fs_ctx *ctx, int64_t *n);
+int fs_lookup_get_records(const fs_ctx *ctx, float *records /* [n][4] */);
+/* getInformationFromLookup(Eigen::Vector3f&, ...) (FisherInfoManager.cpp:264-285): plain table value, NaN on miss */
+int fs_lookup_query(const fs_ctx *ctx, const float p_camera[3], float *value);
+
+int fs_set_fim_params(fs_ctx *ctx, const fs_fim_params *p);
+
+/* Replaces bool FisherInformationManager::isPoseSafe(geometry_msgs::msg::Pose&, bool, float& information)
+ * (FIP/include/.../FisherInfoManager.hpp:125, FIP/src/.../FisherInfoManager.cpp:39-115) for a batch of
+ * poses; `safe = info_ref[i] > threshold` stays with the caller (threshold 550, FisherInfoBTPlugin.cpp:20).
+ *   pose7     [n][7] position xyz + orientation quaternion xyzw (geometry_msgs::Pose order)
+ *   info_ref  [n]    the reference scalar: sum of table value x crowding factor over visible landmarks
+ *   fim21     [n][21] upper triangle (row-major) of the unit-weight 6x6 FIM, or NULL
+ *   trace, logdet [n] or NULL;  n_visible, n_voxels [n] or NULL */
+int fs_score_fim(fs_ctx *ctx, int32_t n, const double *pose7, float *info_ref, float *fim21,
+                 float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels);
+
+/* ---------------------------------------------------------------- fused scoring */
+
+/* Replaces the scoring half of bool CostAssigner::getFrontierCosts(req, res)
+ * (DEP/include/.../CostAssigner.hpp:70, DEP/src/CostAssigner.cpp:73-119): arrival information for every
+ * candidate, then Fisher information at the pose (goal, best yaw) built like
+ * isPoseSafe(Point, Point, bool) builds one (FIP/src/.../FisherInfoManager.cpp:31-37,
+ * DEP/include/.../util/GeometryUtils.hpp:112-124).  Candidates whose status != OK get zero FI.
+ * records [n] host memory, same order as the input list. */
+int fs_score_candidates(fs_ctx *ctx, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                        const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records);
+
+/* Same, with every buffer already resident in HBM (device pointers; frontier_size / blacklisted /
+ * achievable_in may be NULL).  Asynchronous on the context's stream: call fs_synchronize or
+ * synchronise the borrowed stream before reading d_records.  This is the form the multi-GPU
+ * shard runner uses: d_records is the send buffer of the RCCL all-gather. */
+int fs_score_candidates_dev(fs_ctx *ctx, int32_t n, const double *d_goal_xyz, const int32_t *d_frontier_size,
+                            const uint8_t *d_blacklisted, const uint8_t *d_achievable_in, fs_record *d_records);
+
+/* ---------------------------------------------------------------- utility + ranking */
+
+/* Replaces the U1 block of FrontierCostsManager::assignCosts (DEP/src/FrontierCostsManager.cpp:118,126-205)
+ * and the four parallel vectors of GetFrontierCostsResponse (DEP/include/.../CostAssigner.hpp:51-59),
+ * on the GPU.  records [n] host (from fs_score_candidates or gathered from all shards);
+ * path_length / path_heading [n] from the planner (out of scope; inputs here).
+ * Outputs: weighted_cost, arrival_utility, distance_utility [n]; order [n] = candidate indices by
+ * ascending cost (stable).  Returns FS_E_RANGE where the reference would throw. */
+int fs_rank_candidates(fs_ctx *ctx, int32_t n, const fs_record *records, const uint8_t *blacklisted,
+                       const double *path_length, const double *path_heading,
+                       double alpha, double beta, double max_vx, double max_wz,
+                       double *weighted_cost, double *arrival_utility, double *distance_utility,
+                       int32_t *order);
+
+/* ---------------------------------------------------------------- self test */
+
+/* Runs the fp64 primitives the ray set-up relies on (sqrt of exact small integers, division) on the
+ * device and compares them with the host's correctly rounded results bit for bit.
+ * *mismatches = 0 is required for bit-exact ray geometry. */
+int fs_selftest_fp64(fs_ctx *ctx, int32_t max_abs, int64_t *mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

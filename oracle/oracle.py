@@ -1,0 +1,375 @@
+"""ctypes wrapper around oracle/libfso_oracle.so — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle/fso_oracle.h).  The product package `fit-slam_amd` never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfso_oracle.so")
+
+STATUS_OK, STATUS_OFF_MAP, STATUS_BLACKLISTED = 0, 1, 2
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    srcs = [os.path.join(_HERE, f) for f in ("fso_raycast.c", "fso_fisher.c", "fso_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class _Grid(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("origin_x", C.c_double), ("origin_y", C.c_double), ("origin_z", C.c_double),
+                ("resolution", C.c_double), ("cells", C.c_void_p)]
+
+
+class _RayParams(C.Structure):
+    _fields_ = [("max_camera_depth", C.c_double), ("delta_theta", C.c_double), ("camera_fov", C.c_double),
+                ("robot_radius", C.c_double), ("n_rays", C.c_int32), ("n_elev", C.c_int32),
+                ("elev", C.c_void_p),
+                ("obst_min", C.c_int32), ("obst_max", C.c_int32), ("trace_min", C.c_int32), ("trace_max", C.c_int32),
+                ("clamp_to_polygon", C.c_int32), ("polygon", C.c_double * 4)]
+
+
+class _VisParams(C.Structure):
+    _fields_ = [("max_dist", C.c_double), ("max_angle", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.fso_num_yaw_rays.restype = C.c_int32
+        L.fso_num_yaw_rays.argtypes = [C.c_double, C.c_int32]
+        L.fso_theta_list.argtypes = [C.c_double, C.c_int32, C.c_void_p]
+        L.fso_world_to_map.restype = C.c_int
+        L.fso_world_to_map.argtypes = [C.POINTER(_Grid), C.c_double, C.c_double, C.c_double,
+                                       C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.fso_trace_ray.restype = C.c_int
+        L.fso_trace_ray.argtypes = [C.POINTER(_Grid)] + [C.c_double] * 7 + [C.c_int] * 5 + \
+            [C.POINTER(C.c_int32)] * 4 + [C.c_void_p, C.POINTER(C.c_int32)]
+        L.fso_footprint_in_lethal.restype = C.c_int
+        L.fso_footprint_in_lethal.argtypes = [C.POINTER(_Grid), C.c_uint32, C.c_uint32, C.c_uint32, C.c_double]
+        L.fso_arrival_information.restype = C.c_int
+        L.fso_arrival_information.argtypes = [C.POINTER(_Grid), C.POINTER(_RayParams), C.c_int32] + \
+            [C.c_void_p] * 4 + [C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 6
+        L.fso_max_arrival_information.restype = C.c_double
+        L.fso_max_arrival_information.argtypes = [C.POINTER(_Grid), C.POINTER(_RayParams), C.c_double, C.c_double,
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.fso_information_of_point_local.restype = C.c_float
+        L.fso_information_of_point_local.argtypes = [C.c_void_p]
+        L.fso_information_of_point_local_world.restype = C.c_float
+        L.fso_information_of_point_local_world.argtypes = [C.c_void_p, C.c_void_p]
+        L.fso_fim_point_local_f64.argtypes = [C.c_void_p, C.c_void_p]
+        L.fso_voxel_coordinate.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.fso_factor_from_num.restype = C.c_float
+        L.fso_factor_from_num.argtypes = [C.c_int32]
+        L.fso_table_generate.restype = C.c_void_p
+        L.fso_table_generate.argtypes = [C.c_float] * 6
+        L.fso_table_from_records.restype = C.c_void_p
+        L.fso_table_from_records.argtypes = [C.c_void_p, C.c_int64]
+        L.fso_table_num_records.restype = C.c_int64
+        L.fso_table_num_records.argtypes = [C.c_void_p]
+        L.fso_table_copy_records.argtypes = [C.c_void_p, C.c_void_p]
+        L.fso_table_num_entries.restype = C.c_int64
+        L.fso_table_num_entries.argtypes = [C.c_void_p]
+        L.fso_table_find.restype = C.c_float
+        L.fso_table_find.argtypes = [C.c_void_p, C.c_void_p]
+        L.fso_table_free.argtypes = [C.c_void_p]
+        L.fso_pose_to_rt.argtypes = [C.c_void_p] * 3
+        L.fso_yaw_to_quat.argtypes = [C.c_double, C.c_void_p]
+        L.fso_world_to_camera.argtypes = [C.c_void_p] * 4
+        L.fso_is_visible.restype = C.c_int
+        L.fso_is_visible.argtypes = [C.c_void_p, C.POINTER(_VisParams)]
+        L.fso_pose_information.restype = C.c_int
+        L.fso_pose_information.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                           C.POINTER(_VisParams), C.c_int] + [C.c_void_p] * 7
+        L.fso_u1_costs.restype = C.c_int
+        L.fso_u1_costs.argtypes = [C.c_int32] + [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 3
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Grid:
+    """uint8 cells [nz][ny][nx] (nz == 1: the reference's Costmap2D)."""
+    cells: np.ndarray
+    origin: tuple = (0.0, 0.0, 0.0)
+    resolution: float = 0.05
+
+    def __post_init__(self):
+        c = np.ascontiguousarray(self.cells, dtype=np.uint8)
+        if c.ndim == 2:
+            c = c[None]
+        assert c.ndim == 3
+        self.cells = c
+
+    @property
+    def shape(self):
+        return self.cells.shape  # nz, ny, nx
+
+    def c(self) -> _Grid:
+        nz, ny, nx = self.cells.shape
+        return _Grid(nx, ny, nz, float(self.origin[0]), float(self.origin[1]), float(self.origin[2]),
+                     float(self.resolution), self.cells.ctypes.data)
+
+
+@dataclass
+class RayParams:
+    max_camera_depth: float = 2.0
+    delta_theta: float = 0.10
+    camera_fov: float = 1.04
+    robot_radius: float = 0.60
+    n_rays: int = 0
+    elev: tuple = (0.0,)
+    obst: tuple = (240, 254)
+    trace: tuple = (255, 255)
+    clamp_to_polygon: bool = True
+    polygon: tuple = (-1e300, -1e300, 1e300, 1e300)
+    _elev_arr: np.ndarray = field(default=None, repr=False)
+
+    def c(self) -> _RayParams:
+        self._elev_arr = np.ascontiguousarray(self.elev, dtype=np.float64)
+        poly = (C.c_double * 4)(*[float(v) for v in self.polygon])
+        return _RayParams(self.max_camera_depth, self.delta_theta, self.camera_fov, self.robot_radius,
+                          int(self.n_rays), len(self._elev_arr), self._elev_arr.ctypes.data,
+                          int(self.obst[0]), int(self.obst[1]), int(self.trace[0]), int(self.trace[1]),
+                          1 if self.clamp_to_polygon else 0, poly)
+
+    @property
+    def n_yaw(self) -> int:
+        return num_yaw_rays(self.delta_theta, self.n_rays)
+
+    @property
+    def window(self) -> int:
+        return int(self.camera_fov / self.delta_theta)
+
+
+def num_yaw_rays(delta_theta: float, n_rays: int = 0) -> int:
+    return int(lib().fso_num_yaw_rays(delta_theta, n_rays))
+
+
+def theta_list(delta_theta: float, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.float64)
+    lib().fso_theta_list(delta_theta, n, _p(out))
+    return out
+
+
+def world_to_map(grid: Grid, wx, wy, wz=None):
+    if wz is None:
+        wz = grid.origin[2]
+    mx, my, mz = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    g = grid.c()
+    ok = lib().fso_world_to_map(C.byref(g), wx, wy, wz, C.byref(mx), C.byref(my), C.byref(mz))
+    return bool(ok), mx.value, my.value, mz.value
+
+
+def trace_ray(grid: Grid, s, w, max_length_cells, obst=(240, 254), trace=(255, 255), faithful=True):
+    g = grid.c()
+    traced, hit, unknown, allc, nvis = (C.c_int32() for _ in range(5))
+    visited = np.zeros(int(max_length_cells) + 8, dtype=np.uint32)
+    ok = lib().fso_trace_ray(C.byref(g), s[0], s[1], s[2], w[0], w[1], w[2], float(max_length_cells),
+                             obst[0], obst[1], trace[0], trace[1], 1 if faithful else 0,
+                             C.byref(traced), C.byref(hit), C.byref(unknown), C.byref(allc),
+                             _p(visited), C.byref(nvis))
+    return dict(ok=bool(ok), traced=traced.value, hit=bool(hit.value), unknown=unknown.value,
+                all=allc.value, visited=visited[:nvis.value].copy())
+
+
+def footprint_in_lethal(grid: Grid, cx, cy, cz, radius_in_cells) -> bool:
+    g = grid.c()
+    return bool(lib().fso_footprint_in_lethal(C.byref(g), cx, cy, cz, float(radius_in_cells)))
+
+
+def arrival_information(grid: Grid, params: RayParams, goal_xyz, frontier_size=None, blacklisted=None,
+                        achievable_in=None, min_gt=0.0, faithful=False, n_threads=1, want_ray_counts=True):
+    goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+    n = goal.shape[0]
+    p = params.c()
+    g = grid.c()
+    per = params.n_yaw * len(params.elev)
+    fs = None if frontier_size is None else np.ascontiguousarray(frontier_size, dtype=np.int32)
+    bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+    ai = None if achievable_in is None else np.ascontiguousarray(achievable_in, dtype=np.uint8)
+    rc = np.zeros((n, len(params.elev), params.n_yaw), dtype=np.int32) if want_ray_counts else None
+    arrival = np.zeros(n, dtype=np.int32)
+    argmax = np.zeros(n, dtype=np.int32)
+    yaw = np.zeros(n, dtype=np.float64)
+    ach = np.zeros(n, dtype=np.uint8)
+    status = np.zeros(n, dtype=np.int32)
+    rcode = lib().fso_arrival_information(C.byref(g), C.byref(p), n, _p(goal), _p(fs), _p(bl), _p(ai),
+                                          float(min_gt), 1 if faithful else 0, int(n_threads),
+                                          _p(rc), _p(arrival), _p(argmax), _p(yaw), _p(ach), _p(status))
+    if rcode != 0:
+        raise ValueError(f"fso_arrival_information failed: {rcode} (rays {params.n_yaw} < window {params.window}?)")
+    assert per == (rc.shape[1] * rc.shape[2] if rc is not None else per)
+    return dict(ray_counts=rc, arrival=arrival, argmax=argmax, yaw=yaw, achievable=ach, status=status)
+
+
+def max_arrival_information(grid: Grid, params: RayParams, factor_max=1.2, factor_min=0.70):
+    p = params.c()
+    g = grid.c()
+    mx, mn = C.c_double(0.0), C.c_double(0.0)
+    v = lib().fso_max_arrival_information(C.byref(g), C.byref(p), factor_max, factor_min, C.byref(mx), C.byref(mn))
+    return dict(max_value=v, max_gt=mx.value, min_gt=mn.value)
+
+
+def information_of_point_local(p) -> float:
+    a = np.ascontiguousarray(p, dtype=np.float32)
+    return float(lib().fso_information_of_point_local(_p(a)))
+
+
+def information_of_point_local_world(pose7, p_w) -> float:
+    a = np.ascontiguousarray(pose7, dtype=np.float64)
+    b = np.ascontiguousarray(p_w, dtype=np.float32)
+    return float(lib().fso_information_of_point_local_world(_p(a), _p(b)))
+
+
+def fim_point_local_f64(p) -> np.ndarray:
+    a = np.ascontiguousarray(p, dtype=np.float64)
+    F = np.zeros((6, 6), dtype=np.float64)
+    lib().fso_fim_point_local_f64(_p(a), _p(F))
+    return F
+
+
+def voxel_coordinate(x, y, z):
+    key = np.zeros(3, dtype=np.float32)
+    idx = np.zeros(3, dtype=np.int32)
+    lib().fso_voxel_coordinate(float(np.float32(x)), float(np.float32(y)), float(np.float32(z)), _p(key), _p(idx))
+    return key, idx
+
+
+def factor_from_num(k: int) -> float:
+    return float(lib().fso_factor_from_num(int(k)))
+
+
+class Table:
+    """The reference's FI lookup table (.dat: float key[3] + float value, 16 B records)."""
+
+    # DEP/src/fisher_information/GenerateLookupMain.cpp:9
+    REFERENCE_BOUNDS = (0.0, 21.0, -8.5 * 1.732, 8.5 * 1.732, -8.5 * 1.732, 8.5 * 1.732)
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def generate(cls, bounds=None):
+        b = cls.REFERENCE_BOUNDS if bounds is None else bounds
+        return cls(lib().fso_table_generate(*[float(np.float32(v)) for v in b]))
+
+    @classmethod
+    def from_records(cls, records):
+        r = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 4)
+        return cls(lib().fso_table_from_records(_p(r), r.shape[0]))
+
+    @property
+    def records(self) -> np.ndarray:
+        n = lib().fso_table_num_records(self._h)
+        out = np.zeros((n, 4), dtype=np.float32)
+        lib().fso_table_copy_records(self._h, _p(out))
+        return out
+
+    @property
+    def num_entries(self) -> int:
+        return int(lib().fso_table_num_entries(self._h))
+
+    def find(self, key) -> float:
+        k = np.ascontiguousarray(key, dtype=np.float32)
+        return float(lib().fso_table_find(self._h, _p(k)))
+
+    def __del__(self):
+        try:
+            lib().fso_table_free(self._h)
+        except Exception:
+            pass
+
+
+def pose_to_rt(pose7):
+    a = np.ascontiguousarray(pose7, dtype=np.float64)
+    R = np.zeros(9, dtype=np.float32)
+    t = np.zeros(3, dtype=np.float32)
+    lib().fso_pose_to_rt(_p(a), _p(R), _p(t))
+    return R.reshape(3, 3), t
+
+
+def yaw_to_quat(yaw: float) -> np.ndarray:
+    q = np.zeros(4, dtype=np.float64)
+    lib().fso_yaw_to_quat(float(yaw), _p(q))
+    return q
+
+
+def poses_from_yaw(goal_xyz, yaw) -> np.ndarray:
+    goal = np.asarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((goal.shape[0], 7), dtype=np.float64)
+    out[:, :3] = goal
+    for i, y in enumerate(np.asarray(yaw, dtype=np.float64)):
+        out[i, 3:] = yaw_to_quat(y)
+    return out
+
+
+def world_to_camera(R, t, w) -> np.ndarray:
+    Rf = np.ascontiguousarray(R, dtype=np.float32).reshape(9)
+    tf = np.ascontiguousarray(t, dtype=np.float32)
+    wf = np.ascontiguousarray(w, dtype=np.float32)
+    p = np.zeros(3, dtype=np.float32)
+    lib().fso_world_to_camera(_p(Rf), _p(tf), _p(wf), _p(p))
+    return p
+
+
+def is_visible(p, max_dist=14.0, max_angle=1.0) -> bool:
+    a = np.ascontiguousarray(p, dtype=np.float32)
+    v = _VisParams(max_dist, max_angle)
+    return bool(lib().fso_is_visible(_p(a), C.byref(v)))
+
+
+def pose_information(table: Table, landmarks_xyz, pose7, max_dist=14.0, max_angle=1.0, n_threads=1,
+                     want_f64=True):
+    lm = np.ascontiguousarray(landmarks_xyz, dtype=np.float32).reshape(-1, 3)
+    ps = np.ascontiguousarray(pose7, dtype=np.float64).reshape(-1, 7)
+    n, m = ps.shape[0], lm.shape[0]
+    v = _VisParams(max_dist, max_angle)
+    info_ref = np.zeros(n, dtype=np.float32)
+    info64 = np.zeros(n, dtype=np.float64) if want_f64 else None
+    fim = np.zeros((n, 6, 6), dtype=np.float64) if want_f64 else None
+    trace = np.zeros(n, dtype=np.float64) if want_f64 else None
+    logdet = np.zeros(n, dtype=np.float64) if want_f64 else None
+    nvis = np.zeros(n, dtype=np.int32)
+    nvox = np.zeros(n, dtype=np.int32)
+    rc = lib().fso_pose_information(table._h, _p(lm), m, n, _p(ps), C.byref(v), int(n_threads),
+                                    _p(info_ref), _p(info64), _p(fim), _p(trace), _p(logdet), _p(nvis), _p(nvox))
+    assert rc == 0
+    return dict(info_ref=info_ref, info_f64=info64, fim=fim, trace=trace, logdet=logdet,
+                n_visible=nvis, n_voxels=nvox)
+
+
+def u1_costs(arrival, achievable, path_length, path_heading, max_arrival_gt, blacklisted=None,
+             alpha=0.25, beta=1.0, max_vx=0.5, max_wz=0.5):
+    ar = np.ascontiguousarray(arrival, dtype=np.float64)
+    n = ar.shape[0]
+    ac = np.ascontiguousarray(achievable, dtype=np.uint8)
+    bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+    pl = np.ascontiguousarray(path_length, dtype=np.float64)
+    ph = np.ascontiguousarray(path_heading, dtype=np.float64)
+    cost = np.zeros(n); au = np.zeros(n); du = np.zeros(n)
+    rc = lib().fso_u1_costs(n, _p(ar), _p(ac), _p(bl), _p(pl), _p(ph), alpha, beta, max_vx, max_wz,
+                            float(max_arrival_gt), _p(cost), _p(au), _p(du))
+    return rc, dict(weighted_cost=cost, arrival_utility=au, distance_utility=du)

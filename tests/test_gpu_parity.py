@@ -1,0 +1,260 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Integer outputs (per-ray counts, arrival, argmax, achievability, status, visible /
+voxel counts) must be bit-exact; Fisher information within 1e-4 relative (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4   # north_star tolerance for FIM trace / D-optimality / info
+
+
+def _oracle_grid_params(oracle, w, **over):
+    G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+              robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+    kw.update(over)
+    return G, oracle.RayParams(**kw)
+
+
+def _setup_scorer(scorer, w, **over):
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+              robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+    kw.update(over)
+    scorer.set_ray_params(**kw)
+    scorer.upload_grid(w.cells, w.origin, w.resolution)
+    scorer.upload_landmarks(w.landmarks)
+    scorer.set_fim_params(14.0, 1.0)
+
+
+def _assert_arrival_equal(got, want):
+    for k in ("status", "arrival", "argmax", "achievable"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    np.testing.assert_array_equal(got["yaw"], want["yaw"])          # same fp64 expression -> identical bits
+    if got.get("ray_counts") is not None and want.get("ray_counts") is not None:
+        np.testing.assert_array_equal(got["ray_counts"], want["ray_counts"])
+
+
+def test_fp64_primitives_match_host(scorer):
+    """sqrt of exact integers and division on the device == libm hypot / host division, bit for bit."""
+    assert scorer.selftest_fp64(512) == 0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_arrival_reference_defaults_2d(fs, oracle, scorer, seed):
+    """The bit-exact 2-D slice: 63 rays (delta 0.10 accumulated), L = 40, window 10, polygon clamp."""
+    w = fs.synth.make_small_2d(seed)
+    G, P = _oracle_grid_params(oracle, w)
+    _setup_scorer(scorer, w)
+    assert (scorer.n_yaw, scorer.window) == (63, 10)
+    mx_o = oracle.max_arrival_information(G, P)
+    mx_g = scorer.max_arrival()
+    assert mx_g == mx_o
+    want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], faithful=True)
+    got = scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+    _assert_arrival_equal(got, want)
+    assert (want["arrival"] > 0).sum() > 0
+
+
+@pytest.mark.parametrize("name", ["C1_2D", "C1", "C2"])
+def test_arrival_configs(fs, oracle, scorer, name):
+    w = fs.synth.make_workload(name, n_cand=1500 if name == "C2" else None)
+    G, P = _oracle_grid_params(oracle, w)
+    _setup_scorer(scorer, w)
+    mx_o = oracle.max_arrival_information(G, P)
+    assert scorer.max_arrival() == mx_o
+    want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], n_threads=8)
+    got = scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+    _assert_arrival_equal(got, want)
+
+
+def test_arrival_edge_cases(fs, oracle, scorer):
+    """off-map goals, goals on the border, NaN goal, blacklisted, achievable_in = 0, empty list."""
+    w = fs.synth.make_small_2d(21, n=64, n_cand=32)
+    G, P = _oracle_grid_params(oracle, w)
+    _setup_scorer(scorer, w)
+    lo = w.origin[0]
+    hi = w.origin[0] + 64 * w.resolution
+    goals = np.array([[lo - 1.0, 0.0, 0.0], [0.0, hi + 5.0, 0.0], [lo + 1e-9, lo + 1e-9, 0.0],
+                      [hi - 1e-9, hi - 1e-9, 0.0], [np.nan, 0.0, 0.0], [0.0, 0.0, 0.0], [1e30, 0.0, 0.0],
+                      [0.3, -0.2, 0.0]], dtype=np.float64)
+    fsz = np.array([1, 2, 3, 4, 5, 50, 7, 9], dtype=np.int32)
+    bl = np.array([0, 0, 0, 0, 0, 0, 0, 1], dtype=np.uint8)
+    ai = np.array([1, 1, 0, 1, 1, 1, 1, 1], dtype=np.uint8)
+    want = oracle.arrival_information(G, P, goals, fsz, bl, ai, min_gt=50.0, faithful=True)
+    scorer.set_arrival_limits(100.0, 50.0)
+    got = scorer.score_arrival(goals, fsz, bl, ai)
+    _assert_arrival_equal(got, want)
+    assert list(want["status"][[0, 1, 4, 6, 7]]) == [1, 1, 1, 1, 2]
+    empty = scorer.score_arrival(np.zeros((0, 3)))
+    assert empty["arrival"].shape == (0,)
+
+
+def test_arrival_properties(fs, scorer):
+    """Oracle-free properties: all-unknown grid -> every candidate reaches the geometric maximum;
+    all-free grid -> zero; a wall of lethal cells blocks exactly the rays that cross it."""
+    n = 128
+    res = 0.05
+    origin = (-n * res / 2, -n * res / 2, 0.0)
+    scorer.set_ray_params(polygon=(-100, -100, 100, 100))
+    goals = np.array([[0.0, 0.0, 0.0], [0.5, -0.3, 0.0], [-0.71, 0.42, 0.0]])
+    scorer.upload_grid(np.full((n, n), 255, np.uint8), origin, res)
+    mx = scorer.max_arrival()
+    got = scorer.score_arrival(goals)
+    assert mx["max_value"] > 0
+    # interior goals on an all-unknown map see the same count geometry up to sub-cell offsets
+    assert np.all(np.abs(got["arrival"] - mx["max_value"]) <= 12)
+    assert got["arrival"][0] == mx["max_value"]
+    scorer.upload_grid(np.zeros((n, n), np.uint8), origin, res)
+    got = scorer.score_arrival(goals)
+    assert np.all(got["arrival"] == 0) and np.all(got["ray_counts"] == 0)
+    cells = np.full((n, n), 255, np.uint8)
+    cells[:, n // 2 + 10] = 254            # a wall 10 cells to the +x side of the centre
+    scorer.upload_grid(cells, origin, res)
+    got = scorer.score_arrival(goals[:1])
+    rc = got["ray_counts"][0, 0]
+    assert rc[0] == 10                      # theta = 0: cells 0..9 unknown, cell 10 is the wall
+    assert rc[31] >= 40                     # theta ~ pi: unobstructed, ~40 steps + the final visit
+
+
+def test_fim_known_answers(scorer):
+    """SURVEY.md App. C.1 closed form 2 + 2/|p|^2 through the table + single landmarks."""
+    pts = np.array([[0.3, 0, 0], [0.3, 0.3, 0.3], [1.2, -0.9, 0.3], [3, 0.3, -0.6]], dtype=np.float32)
+    expect = [24.222222, 9.407407, 2.854701, 2.211640]
+    pose = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
+    scorer.set_fim_params(14.0, 1.3)
+    for p, e in zip(pts, expect):
+        scorer.upload_landmarks(p[None])
+        r = scorer.score_fim(pose)
+        assert r["n_visible"][0] == 1 and r["n_voxels"][0] == 1
+        assert abs(r["info_ref"][0] - e) <= 2e-6 * e
+        n2 = float(np.dot(p, p))
+        assert abs(r["trace"][0] - (2 + 2 / n2)) <= 1e-5 * (2 + 2 / n2)
+    # crowding: k landmarks in one voxel -> info * sum_{j<=k} exp(1 - j^0.8)   (App. C.4)
+    scorer.upload_landmarks(np.tile(np.array([[1.2, -0.9, 0.3]], np.float32), (5, 1)))
+    r = scorer.score_fim(pose)
+    S5 = sum(np.exp(1 - j ** 0.8) for j in range(1, 6))
+    assert r["n_visible"][0] == 5 and r["n_voxels"][0] == 1
+    assert abs(r["info_ref"][0] - 2.854701 * S5) < 2e-4
+
+
+def _check_fim(got, want, n_lm):
+    np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
+    np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
+    scale = np.maximum(np.abs(want["info_f64"]), 1e-6)
+    assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / scale) <= REL
+    # the reference's own float32 running sum drifts from the exact sum; allow its drift on top
+    drift = np.abs(want["info_ref"] - want["info_f64"]) / scale
+    assert np.max(np.abs(got["info_ref"] - want["info_ref"]) / scale - drift) <= REL
+    tr = np.maximum(np.abs(want["trace"]), 1e-6)
+    assert np.max(np.abs(got["trace"] - want["trace"]) / tr) <= REL
+    # D-optimality has no reference counterpart: it is checked against the float64 oracle.
+    # fp32 block sums carry ~1e-6 relative error per entry, amplified by the FIM's condition number.
+    ok = np.isfinite(want["logdet"])
+    lam = np.linalg.eigvalsh(want["fim"])
+    cond = lam[:, -1] / np.maximum(lam[:, 0], 1e-300)
+    sure = ok & (cond < 1e5)
+    np.testing.assert_array_equal(np.isfinite(got["logdet"])[sure], True)
+    np.testing.assert_array_equal(np.isfinite(got["logdet"])[want["n_visible"] < 3], False)
+    both = ok & np.isfinite(got["logdet"])
+    if both.any():
+        tol = REL * np.maximum(1.0, np.abs(want["logdet"][both])) + 1e-6 * cond[both]
+        assert np.all(np.abs(got["logdet"][both] - want["logdet"][both]) <= tol)
+    if got.get("fim21") is not None:
+        iu = np.triu_indices(6)
+        wantF = want["fim"][:, iu[0], iu[1]]
+        mag = np.maximum(np.abs(wantF).max(axis=1, keepdims=True), 1e-6)
+        assert np.max(np.abs(got["fim21"] - wantF) / mag) <= REL
+
+
+@pytest.mark.parametrize("name,n_pose", [("C1", 200), ("C2", 300)])
+def test_fim_explicit_poses(fs, oracle, scorer, ref_table, name, n_pose):
+    w = fs.synth.make_workload(name, n_cand=n_pose)
+    rng = np.random.default_rng(5)
+    yaw = rng.uniform(-np.pi, np.pi, size=n_pose)
+    poses = oracle.poses_from_yaw(w.goals, yaw)
+    # a few general (non-yaw-only) orientations
+    q = rng.normal(size=(8, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses[:8, 3:] = q
+    _setup_scorer(scorer, w)
+    want = oracle.pose_information(ref_table, w.landmarks, poses, 14.0, 1.0, n_threads=8)
+    got = scorer.score_fim(poses)
+    _check_fim(got, want, w.landmarks.shape[0])
+
+
+def test_fim_cone_modes_and_empty(fs, oracle, scorer, ref_table):
+    w = fs.synth.make_workload("C1", n_cand=40)
+    poses = oracle.poses_from_yaw(w.goals, np.linspace(-3, 3, 40))
+    _setup_scorer(scorer, w)
+    for max_dist, max_angle in [(14.0, 4.0), (3.0, 2.2), (1.0, 0.2), (6.0, np.pi / 2)]:
+        scorer.set_fim_params(max_dist, max_angle)
+        want = oracle.pose_information(ref_table, w.landmarks, poses, max_dist, max_angle, n_threads=4)
+        got = scorer.score_fim(poses)
+        _check_fim(got, want, w.landmarks.shape[0])
+    scorer.set_fim_params(14.0, 1.0)
+    scorer.upload_landmarks(np.zeros((0, 3), np.float32))
+    got = scorer.score_fim(poses[:3])
+    assert np.all(got["info_ref"] == 0) and np.all(got["n_visible"] == 0) and np.all(np.isneginf(got["logdet"]))
+
+
+def test_fim_hash_overflow_pass(fs, oracle, scorer, ref_table):
+    """More distinct voxels than the 32768-slot LDS table: the HBM-table pass must take over."""
+    rng = np.random.default_rng(9)
+    m = 110_000
+    r = rng.uniform(0.5, 13.5, size=m) ** (1 / 1.0)
+    u = rng.normal(size=(m, 3)); u[:, 0] = np.abs(u[:, 0]) * 3 + 0.5
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    lm = (u * r[:, None]).astype(np.float32)
+    poses = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0.1, -0.2, 0.05, 0, 0, 0.1, 0.995]])
+    scorer.upload_landmarks(lm)
+    scorer.set_fim_params(14.0, 1.3)
+    want = oracle.pose_information(ref_table, lm, poses, 14.0, 1.3)
+    assert want["n_voxels"].max() > 33_000
+    got = scorer.score_fim(poses)
+    _check_fim(got, want, m)
+
+
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_fused_candidates(fs, oracle, scorer, ref_table, name):
+    w = fs.synth.make_workload(name, n_cand=600 if name == "C2" else None)
+    G, P = _oracle_grid_params(oracle, w)
+    _setup_scorer(scorer, w)
+    mx = oracle.max_arrival_information(G, P)
+    assert scorer.max_arrival() == mx
+    arr = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx["min_gt"], n_threads=8)
+    poses = oracle.poses_from_yaw(w.goals, arr["yaw"])
+    fim = oracle.pose_information(ref_table, w.landmarks, poses, 14.0, 1.0, n_threads=8)
+    rec = scorer.score_candidates(w.goals, w.frontier_size, w.blacklisted)
+    ok = arr["status"] == 0
+    np.testing.assert_array_equal(rec["arrival"], arr["arrival"])
+    np.testing.assert_array_equal(rec["argmax"], arr["argmax"])
+    np.testing.assert_array_equal(fs.capi.record_status(rec), arr["status"])
+    np.testing.assert_array_equal(fs.capi.record_achievable(rec), arr["achievable"])
+    np.testing.assert_array_equal(rec["yaw"], arr["yaw"].astype(np.float32))
+    np.testing.assert_array_equal(rec["n_visible"][ok], fim["n_visible"][ok])
+    np.testing.assert_array_equal(fs.capi.record_nvoxels(rec)[ok], np.minimum(fim["n_voxels"][ok], 65535))
+    assert np.all(rec["info_ref"][~ok] == 0) and np.all(rec["n_visible"][~ok] == 0)
+    scale = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
+    assert np.max(np.abs(rec["info_ref"][ok] - fim["info_f64"][ok]) / scale) <= REL
+    assert np.max(np.abs(rec["trace"][ok] - fim["trace"][ok]) / np.maximum(fim["trace"][ok], 1e-6)) <= REL
+
+
+def test_rank_matches_oracle(fs, oracle, scorer):
+    w = fs.synth.make_workload("C1")
+    G, P = _oracle_grid_params(oracle, w)
+    _setup_scorer(scorer, w)
+    # C1's 3.2 m map cannot hold the calibration fan (max_arrival = 0): set limits by hand
+    scorer.set_arrival_limits(400.0, 40.0)
+    rec = scorer.score_candidates(w.goals, w.frontier_size, w.blacklisted)
+    rng = np.random.default_rng(3)
+    n = rec.shape[0]
+    plen = rng.uniform(0.5, 30.0, size=n)
+    phead = rng.uniform(0.0, np.pi, size=n)
+    rc, want = oracle.u1_costs(rec["arrival"].astype(np.float64), fs.capi.record_achievable(rec), plen, phead, 400.0,
+                               blacklisted=w.blacklisted)
+    assert rc == 0
+    got = scorer.rank_candidates(rec, plen, phead, blacklisted=w.blacklisted)
+    for k in ("weighted_cost", "arrival_utility", "distance_utility"):
+        np.testing.assert_array_equal(got[k], want[k])
+    np.testing.assert_array_equal(got["order"], np.argsort(want["weighted_cost"], kind="stable"))
