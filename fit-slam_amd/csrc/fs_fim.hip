@@ -144,7 +144,7 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
         const float zs[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            // p = R^T (w - t), op order of the spec (oracle: fso_world_to_camera)
+            // p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
             const float dx = xs[k] - t[0], dy = ys[k] - t[1], dz = zs[k] - t[2];
             const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
             const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));

@@ -1,0 +1,63 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py).
+
+not-gpu: the oracle must still reproduce them (guards the checker against drift).
+gpu:     the HIP path, through the C ABI, must reproduce them (integers bit-exact, FI within 1e-4)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+INT_KEYS = ("ray_counts", "arrival", "argmax", "achievable", "status")
+
+
+def _params(z):
+    return dict(max_camera_depth=float(z["max_camera_depth"]), delta_theta=float(z["delta_theta"]),
+                camera_fov=float(z["camera_fov"]), robot_radius=float(z["robot_radius"]), n_rays=int(z["n_rays"]),
+                elev=tuple(float(e) for e in z["elev"]), polygon=tuple(float(v) for v in z["polygon"]))
+
+
+def test_fixtures_exist():
+    assert len(GOLDEN) >= 2
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_reproduces_golden(oracle, ref_table, path):
+    z = np.load(path)
+    G = oracle.Grid(z["cells"], origin=tuple(z["origin"]), resolution=float(z["resolution"]))
+    P = oracle.RayParams(**_params(z))
+    mx = oracle.max_arrival_information(G, P)
+    assert (mx["max_value"], mx["max_gt"], mx["min_gt"]) == (float(z["max_value"]), float(z["max_gt"]), float(z["min_gt"]))
+    arr = oracle.arrival_information(G, P, z["goals"], z["frontier_size"], z["blacklisted"], min_gt=mx["min_gt"], n_threads=4)
+    for k in INT_KEYS:
+        np.testing.assert_array_equal(arr[k], z[k], err_msg=k)
+    np.testing.assert_array_equal(arr["yaw"], z["yaw"])
+    fim = oracle.pose_information(ref_table, z["landmarks"], oracle.poses_from_yaw(z["goals"], arr["yaw"]), 14.0, 1.0)
+    np.testing.assert_array_equal(fim["n_visible"], z["n_visible"])
+    np.testing.assert_array_equal(fim["n_voxels"], z["n_voxels"])
+    np.testing.assert_array_equal(fim["info_ref"], z["info_ref"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_hip_reproduces_golden(fs, scorer, path):
+    z = np.load(path)
+    scorer.set_ray_params(**_params(z))
+    scorer.upload_grid(z["cells"], tuple(z["origin"]), float(z["resolution"]))
+    scorer.upload_landmarks(z["landmarks"])
+    scorer.set_fim_params(14.0, 1.0)
+    mx = scorer.max_arrival()
+    assert (mx["max_value"], mx["max_gt"], mx["min_gt"]) == (float(z["max_value"]), float(z["max_gt"]), float(z["min_gt"]))
+    arr = scorer.score_arrival(z["goals"], z["frontier_size"], z["blacklisted"])
+    for k in INT_KEYS:
+        np.testing.assert_array_equal(arr[k], z[k], err_msg=k)
+    np.testing.assert_array_equal(arr["yaw"], z["yaw"])
+    rec = scorer.score_candidates(z["goals"], z["frontier_size"], z["blacklisted"])
+    ok = z["status"] == 0
+    np.testing.assert_array_equal(rec["arrival"], z["arrival"])
+    np.testing.assert_array_equal(rec["n_visible"][ok], z["n_visible"][ok])
+    np.testing.assert_array_equal(fs.capi.record_nvoxels(rec)[ok], z["n_voxels"][ok])
+    sc = np.maximum(np.abs(z["info_f64"][ok]), 1e-6)
+    assert np.max(np.abs(rec["info_ref"][ok] - z["info_f64"][ok]) / sc) <= 1e-4
+    assert np.max(np.abs(rec["trace"][ok] - z["trace"][ok]) / np.maximum(z["trace"][ok], 1e-6)) <= 1e-4
