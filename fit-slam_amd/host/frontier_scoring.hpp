@@ -1,0 +1,572 @@
+// frontier_scoring.hpp — C++17 host-side mirror of the reference's scoring interface, implemented on
+// the C ABI of include/fitslam_frontier.h (header-only; link with -lfitslam_frontier).
+//
+// FIT-SLAM's own host code is ROS 2 C++ (rclcpp / nav2 / pluginlib); that toolchain is absent from the
+// build image, so this mirror keeps the reference's class and method names, argument meaning and error
+// behaviour with plain C++ types in place of the ROS message types:
+//   frontier_exploration::Costmap2D                 <- nav2_costmap_2d::Costmap2D accessors the path uses
+//   frontier_exploration::Frontier / FrontierPtr    <- DEP/include/frontier_exploration/Frontier.hpp:39-134
+//   frontier_exploration::FrontierCostCalculator    <- DEP/include/.../CostCalculator.hpp:46-136, DEP/src/CostCalculator.cpp:5-191,512-520
+//   frontier_exploration::FrontierCostsManager      <- DEP/src/FrontierCostsManager.cpp:47-223
+//   frontier_exploration::CostAssigner (+ Request/Response) <- DEP/include/.../CostAssigner.hpp:43-100, DEP/src/CostAssigner.cpp:29-167
+//   roadmap_explorer::FisherInformationManager      <- FIP/include/.../FisherInfoManager.hpp:72-145, FIP/src/.../FisherInfoManager.cpp:31-324
+// (DEP/ = dev_ws/src/DEPRECATED/frontier_exploration/frontier_exploration/, FIP/ = dev_ws/src/fit-slam2/fisher_information_plugins/)
+//
+// What differs from the reference, by design: the per-frontier loop of assignCosts
+// (FrontierCostsManager.cpp:74-119) is ONE batched GPU call; the path planner (roadmap A*, out of scope)
+// is a pluggable callback defaulting to setPlanForFrontierEuclidean (CostCalculator.cpp:446-484); the
+// landmark service round-trip (FisherInfoManager.cpp:52-77) is replaced by a cloud staged once with
+// setLandmarks().  No scoring is ever computed on the CPU here.
+#ifndef FITSLAM_FRONTIER_SCORING_HPP_
+#define FITSLAM_FRONTIER_SCORING_HPP_
+
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <limits>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fitslam_frontier.h"
+
+namespace frontier_exploration
+{
+struct Point { double x = 0, y = 0, z = 0; };
+struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
+struct Pose { Point position; Quaternion orientation; };
+struct PoseStamped { Pose pose; };
+
+// nav2_util::geometry_utils::orientationAroundZAxis == tf2::Quaternion::setRPY(0, 0, angle)
+inline Quaternion orientationAroundZAxis(double angle)
+{
+    Quaternion q;
+    q.x = 0.0; q.y = 0.0; q.z = std::sin(angle * 0.5); q.w = std::cos(angle * 0.5);
+    return q;
+}
+
+// DEP/include/.../util/GeometryUtils.hpp:112-124
+inline void getRelativePoseGivenTwoPoints(const Point &point_from, const Point &point_to, Pose &oriented_pose)
+{
+    const double dx = point_to.x - point_from.x, dy = point_to.y - point_from.y;
+    oriented_pose.position = point_from;
+    oriented_pose.orientation = orientationAroundZAxis(std::atan2(dy, dx));
+}
+
+// The subset of nav2_costmap_2d::Costmap2D the path touches, with an optional z extent (3-D extension).
+class Costmap2D
+{
+public:
+    Costmap2D(unsigned int size_x, unsigned int size_y, double resolution, double origin_x, double origin_y,
+              unsigned char default_value = 0, unsigned int size_z = 1, double origin_z = 0.0)
+        : size_x_(size_x), size_y_(size_y), size_z_(size_z), resolution_(resolution),
+          origin_x_(origin_x), origin_y_(origin_y), origin_z_(origin_z),
+          costmap_(static_cast<size_t>(size_x) * size_y * size_z, default_value) {}
+    unsigned char getCost(unsigned int mx, unsigned int my) const { return costmap_[getIndex(mx, my)]; }
+    unsigned char getCost(unsigned int index) const { return costmap_[index]; }
+    void setCost(unsigned int mx, unsigned int my, unsigned char cost) { costmap_[getIndex(mx, my)] = cost; }
+    unsigned char *getCharMap() { return costmap_.data(); }
+    const unsigned char *getCharMap() const { return costmap_.data(); }
+    unsigned int getIndex(unsigned int mx, unsigned int my) const { return my * size_x_ + mx; }
+    void indexToCells(unsigned int index, unsigned int &mx, unsigned int &my) const { my = index / size_x_; mx = index - (my * size_x_); }
+    bool worldToMap(double wx, double wy, unsigned int &mx, unsigned int &my) const
+    {
+        if (wx < origin_x_ || wy < origin_y_) return false;
+        mx = static_cast<unsigned int>((wx - origin_x_) / resolution_);
+        my = static_cast<unsigned int>((wy - origin_y_) / resolution_);
+        return mx < size_x_ && my < size_y_;
+    }
+    void mapToWorld(unsigned int mx, unsigned int my, double &wx, double &wy) const
+    {
+        wx = origin_x_ + (mx + 0.5) * resolution_;
+        wy = origin_y_ + (my + 0.5) * resolution_;
+    }
+    unsigned int getSizeInCellsX() const { return size_x_; }
+    unsigned int getSizeInCellsY() const { return size_y_; }
+    unsigned int getSizeInCellsZ() const { return size_z_; }
+    double getSizeInMetersX() const { return (size_x_ - 1 + 0.5) * resolution_; }
+    double getSizeInMetersY() const { return (size_y_ - 1 + 0.5) * resolution_; }
+    double getOriginX() const { return origin_x_; }
+    double getOriginY() const { return origin_y_; }
+    double getOriginZ() const { return origin_z_; }
+    double getResolution() const { return resolution_; }
+    std::mutex &getMutex() { return mutex_; }
+
+private:
+    unsigned int size_x_, size_y_, size_z_;
+    double resolution_, origin_x_, origin_y_, origin_z_;
+    std::vector<unsigned char> costmap_;
+    std::mutex mutex_;
+};
+
+// DEP/include/.../Frontier.hpp:39-134 — every getter throws std::runtime_error while its field is unset.
+class Frontier
+{
+public:
+    Frontier() : is_achievable(true), is_blacklisted(false) {}
+    void setUID(size_t uid) { unique_id = uid; }
+    void setSize(int sz) { size = sz; }
+    void setGoalPoint(Point gp) { goal_point = gp; }
+    void setGoalPoint(double x, double y) { Point p; p.x = x; p.y = y; goal_point = p; }
+    void setGoalOrientation(double theta) { theta_s_star = theta; best_orientation = orientationAroundZAxis(theta); }
+    void setArrivalInformation(double info) { information = info; }
+    void setPathLength(double pl) { path_length = pl; }
+    void setPathLengthInM(double pl) { path_length_m = pl; }
+    void setPathHeading(double h) { path_heading = h; }
+    void setFisherInformation(double fi) { fisher_information_in_path = fi; }
+    void setCost(std::string name, double value) { costs[name] = value; }
+    void setWeightedCost(double c) { weighted_cost = c; }
+    void setAchievability(bool v) { is_achievable = v; }
+    void setBlacklisted(bool v) { is_blacklisted = v; }
+    size_t getUID() const { return need(unique_id, "unique_id"); }
+    int getSize() const { return need(size, "size"); }
+    const Point &getGoalPoint() const { return need(goal_point, "goal_point"); }
+    const Quaternion &getGoalOrientation() const { return need(best_orientation, "best_orientation"); }
+    double getGoalYaw() const { return need(theta_s_star, "theta_s_star"); }
+    double getArrivalInformation() const { return need(information, "information"); }
+    double getPathLength() const { return need(path_length, "path_length"); }
+    double getPathLengthInM() const { return need(path_length_m, "path_length_m"); }
+    double getPathHeading() const { return need(path_heading, "path_heading"); }
+    double getFisherInformation() const { return need(fisher_information_in_path, "fisher_information_in_path"); }
+    double getCost(const std::string &name) const
+    {
+        auto it = costs.find(name);
+        if (it == costs.end()) throw std::runtime_error("Cost " + name + " is not set");
+        return it->second;
+    }
+    double getWeightedCost() const { return need(weighted_cost, "weighted_cost"); }
+    bool isAchievable() const { return is_achievable; }
+    bool isBlacklisted() const { return is_blacklisted; }
+    bool operator==(const Frontier &o) const { return getUID() == o.getUID(); }
+
+private:
+    template <typename T>
+    static const T &need(const std::optional<T> &v, const char *what)
+    {
+        if (!v) throw std::runtime_error(std::string("Frontier field is null: ") + what);
+        return *v;
+    }
+    std::optional<size_t> unique_id;
+    std::optional<int> size;
+    std::optional<Point> goal_point;
+    std::optional<Quaternion> best_orientation;
+    std::optional<double> theta_s_star, information, path_length, path_length_m, path_heading,
+        fisher_information_in_path, weighted_cost;
+    bool is_achievable, is_blacklisted;
+    std::map<std::string, double> costs;
+};
+using FrontierPtr = std::shared_ptr<Frontier>;
+
+// RAII owner of one fs_ctx (one GPU, one stream); shared by the mirror classes.
+class ScoringContext
+{
+public:
+    explicit ScoringContext(int device = 0)
+    {
+        const int rc = fs_ctx_create(device, nullptr, &ctx_);
+        if (rc != FS_OK) throw std::runtime_error("fs_ctx_create failed: no MI355X (gfx950) device or HIP runtime; there is no CPU fallback");
+    }
+    ~ScoringContext() { fs_ctx_destroy(ctx_); }
+    ScoringContext(const ScoringContext &) = delete;
+    ScoringContext &operator=(const ScoringContext &) = delete;
+    fs_ctx *get() const { return ctx_; }
+    void check(int rc, const char *what) const
+    {
+        if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_last_error(ctx_));
+    }
+
+private:
+    fs_ctx *ctx_ = nullptr;
+};
+
+class FrontierCostCalculator
+{
+public:
+    // DEP/src/CostCalculator.cpp:5-21 — parameters costCalculator/{max_camera_depth,delta_theta,camera_fov} and
+    // Costmap2DROS::getRobotRadius(); the costmap pointer is kept, the grid is snapshotted by updateCostmap().
+    FrontierCostCalculator(std::shared_ptr<ScoringContext> ctx, std::shared_ptr<Costmap2D> costmap,
+                           double max_camera_depth = 2.0, double delta_theta = 0.10, double camera_fov = 1.04,
+                           double robot_radius = 0.60, double factor_of_max_is_min = 0.70)
+        : ctx_(std::move(ctx)), exploration_costmap_(std::move(costmap)), MAX_CAMERA_DEPTH(max_camera_depth),
+          DELTA_THETA(delta_theta), CAMERA_FOV(camera_fov), robot_radius_(robot_radius), factor_min_(factor_of_max_is_min)
+    {
+        polygon_[0] = polygon_[1] = -std::numeric_limits<double>::max();
+        polygon_[2] = polygon_[3] = std::numeric_limits<double>::max();
+        pushParams();
+        updateCostmap();
+    }
+
+    // Snapshot the costmap into HBM (the reference reads the live costmap without taking its mutex,
+    // ExplorationBT.cpp:171,195 lock only the search; here the copy is the explicit snapshot point).
+    void updateCostmap()
+    {
+        std::lock_guard<std::mutex> lock(exploration_costmap_->getMutex());
+        const double origin[3] = {exploration_costmap_->getOriginX(), exploration_costmap_->getOriginY(), exploration_costmap_->getOriginZ()};
+        ctx_->check(fs_upload_grid(ctx_->get(), exploration_costmap_->getCharMap(), (int32_t)exploration_costmap_->getSizeInCellsX(),
+                                   (int32_t)exploration_costmap_->getSizeInCellsY(), (int32_t)exploration_costmap_->getSizeInCellsZ(),
+                                   origin, exploration_costmap_->getResolution()), "fs_upload_grid");
+        if (arrival_info_limits_set_) ctx_->check(fs_set_arrival_limits(ctx_->get(), max_arrival_info_gt_, min_arrival_info_gt_), "fs_set_arrival_limits");
+    }
+
+    // DEP/src/CostCalculator.cpp:23-121 for one frontier.
+    void setArrivalInformationForFrontier(FrontierPtr &frontier, std::vector<double> &polygon_xy_min_max)
+    {
+        std::vector<FrontierPtr> one{frontier};
+        setArrivalInformationForFrontiers(one, polygon_xy_min_max);
+    }
+
+    // The same for a whole list in one GPU call (replaces the serial loop of FrontierCostsManager.cpp:74-119).
+    void setArrivalInformationForFrontiers(std::vector<FrontierPtr> &frontiers, std::vector<double> &polygon_xy_min_max)
+    {
+        if (polygon_xy_min_max.size() >= 4) setPolygon(polygon_xy_min_max);
+        const int32_t n = (int32_t)frontiers.size();
+        if (n == 0) return;
+        std::vector<double> goal(3 * (size_t)n);
+        std::vector<int32_t> fsize(n), arrival(n), argmax(n), status(n);
+        std::vector<uint8_t> ach_in(n), ach(n);
+        std::vector<double> yaw(n);
+        for (int32_t i = 0; i < n; ++i) {
+            const Point &g = frontiers[i]->getGoalPoint();
+            goal[3 * i] = g.x; goal[3 * i + 1] = g.y; goal[3 * i + 2] = g.z;
+            fsize[i] = frontiers[i]->getSize();
+            ach_in[i] = frontiers[i]->isAchievable();
+        }
+        ctx_->check(fs_score_arrival(ctx_->get(), n, goal.data(), fsize.data(), nullptr, ach_in.data(), nullptr, arrival.data(),
+                                     argmax.data(), yaw.data(), ach.data(), status.data()), "fs_score_arrival");
+        for (int32_t i = 0; i < n; ++i) {
+            frontiers[i]->setArrivalInformation((double)arrival[i]);      // :52 / :112
+            frontiers[i]->setGoalOrientation(yaw[i]);                      // :53 / :119
+            frontiers[i]->setAchievability(ach[i] != 0);                   // :78-82, :114-118
+        }
+    }
+
+    // DEP/src/CostCalculator.cpp:123-191 — cached after the first success, returns 0.0 afterwards.
+    double setMaxArrivalInformation()
+    {
+        if (arrival_info_limits_set_) return 0.0;
+        double max_value = 0, max_gt = 0, min_gt = 0;
+        ctx_->check(fs_max_arrival(ctx_->get(), &max_value, &max_gt, &min_gt), "fs_max_arrival");
+        if (max_value == 0.0) return 0;                                     // (0,0) off the map: limits stay unset
+        arrival_info_limits_set_ = true;
+        max_arrival_info_gt_ = max_gt;
+        min_arrival_info_gt_ = min_gt;
+        return max_value;
+    }
+
+    // CostCalculator.cpp:446-484 — the stand-in planner (the roadmap A* is out of scope).
+    void setPlanForFrontierEuclidean(Pose start_pose_w, FrontierPtr &goal_point_w)
+    {
+        const double dmax = std::numeric_limits<double>::max();
+        auto unreachable = [&]() {
+            goal_point_w->setAchievability(false);
+            goal_point_w->setPathLength(dmax); goal_point_w->setPathLengthInM(dmax); goal_point_w->setPathHeading(dmax);
+            goal_point_w->setFisherInformation(0);
+        };
+        if (goal_point_w->isAchievable() == false) { unreachable(); return; }
+        const Point &g = goal_point_w->getGoalPoint();
+        const double length = std::sqrt(std::pow(start_pose_w.position.x - g.x, 2) + std::pow(start_pose_w.position.y - g.y, 2));
+        if (length < 0.5) { unreachable(); return; }
+        goal_point_w->setAchievability(true);
+        const Quaternion &q = start_pose_w.orientation;
+        double robot_yaw = std::atan2(2.0 * (q.w * q.z + q.x * q.y), 1.0 - 2.0 * (q.y * q.y + q.z * q.z));
+        if (robot_yaw < 0) robot_yaw += M_PI * 2;
+        double goal_yaw = std::atan2(g.y - start_pose_w.position.y, g.x - start_pose_w.position.x);
+        if (goal_yaw < 0) goal_yaw += M_PI * 2;
+        double path_heading = std::abs(robot_yaw - goal_yaw);
+        if (path_heading > M_PI) path_heading = (2 * M_PI) - path_heading;
+        goal_point_w->setPathLength(length); goal_point_w->setPathLengthInM(length); goal_point_w->setPathHeading(path_heading);
+        goal_point_w->setFisherInformation(0.0);
+    }
+
+    // CostCalculator.cpp:512-520 / CostCalculator.hpp:90-116
+    void recomputeNormalizationFactors(FrontierPtr &frontier)
+    {
+        if (!frontier->isAchievable()) return;
+        min_traversable_distance = std::min(min_traversable_distance, frontier->getPathLength());
+        max_traversable_distance = std::max(max_traversable_distance, frontier->getPathLength());
+        min_arrival_info_per_frontier = std::min(min_arrival_info_per_frontier, frontier->getArrivalInformation());
+        max_arrival_info_per_frontier = std::max(max_arrival_info_per_frontier, frontier->getArrivalInformation());
+    }
+    double getMinPlanDistance() { return min_traversable_distance; }
+    double getMaxPlanDistance() { return max_traversable_distance; }
+    double getMinArrivalInformation() { return min_arrival_info_per_frontier; }
+    double getMaxArrivalInformation() { return max_arrival_info_gt_; }      // sic: the *_gt_ value (CostCalculator.hpp:105-108)
+    double getMinArrivalInformationGT() { return min_arrival_info_gt_; }
+    void reset()
+    {
+        min_traversable_distance = std::numeric_limits<double>::max(); max_traversable_distance = -1.0;
+        min_arrival_info_per_frontier = std::numeric_limits<double>::max(); max_arrival_info_per_frontier = -1.0;
+    }
+    std::shared_ptr<ScoringContext> context() const { return ctx_; }
+
+private:
+    void setPolygon(const std::vector<double> &p)
+    {
+        bool changed = false;
+        for (int i = 0; i < 4; ++i) { changed |= (polygon_[i] != p[i]); polygon_[i] = p[i]; }
+        if (changed) pushParams();
+    }
+    void pushParams()
+    {
+        fs_ray_params p{};
+        p.max_camera_depth = MAX_CAMERA_DEPTH; p.delta_theta = DELTA_THETA; p.camera_fov = CAMERA_FOV; p.robot_radius = robot_radius_;
+        p.n_rays = 0; p.n_elev = 1; p.elev[0] = 0.0;
+        p.obst_min = 240; p.obst_max = 254; p.trace_min = 255; p.trace_max = 255;    // CostCalculator.cpp:40
+        p.factor_max = 1.2; p.factor_min = factor_min_;                              // :186-188
+        for (int i = 0; i < 4; ++i) p.polygon[i] = polygon_[i];
+        ctx_->check(fs_set_ray_params(ctx_->get(), &p), "fs_set_ray_params");
+        if (arrival_info_limits_set_) ctx_->check(fs_set_arrival_limits(ctx_->get(), max_arrival_info_gt_, min_arrival_info_gt_), "fs_set_arrival_limits");
+    }
+
+    std::shared_ptr<ScoringContext> ctx_;
+    std::shared_ptr<Costmap2D> exploration_costmap_;
+    double MAX_CAMERA_DEPTH, DELTA_THETA, CAMERA_FOV, robot_radius_, factor_min_;
+    double polygon_[4];
+    double min_traversable_distance = std::numeric_limits<double>::max(), max_traversable_distance = 0.0;
+    double min_arrival_info_per_frontier = std::numeric_limits<double>::max(), max_arrival_info_per_frontier = 0.0;
+    double max_arrival_info_gt_ = 0.0, min_arrival_info_gt_ = 0.0;
+    bool arrival_info_limits_set_ = false;
+};
+
+class FrontierCostsManager
+{
+public:
+    using Planner = std::function<void(const Pose &start_pose_w, FrontierPtr &frontier)>;
+
+    // DEP/src/FrontierCostsManager.cpp:6-23 — parameters frontierCostsManager/{alpha,beta,vx_max,wz_max}.
+    FrontierCostsManager(std::shared_ptr<ScoringContext> ctx, std::shared_ptr<Costmap2D> costmap,
+                         double alpha = 0.25, double beta = 1.0, double vx_max = 0.5, double wz_max = 0.5)
+        : alpha_(alpha), beta_(beta), max_vx_(vx_max), max_wx_(wz_max),
+          costCalculator_(std::make_shared<FrontierCostCalculator>(std::move(ctx), std::move(costmap))) {}
+
+    void setPlanner(Planner p) { planner_ = std::move(p); }
+    std::shared_ptr<FrontierCostCalculator> getCostCalculator() { return costCalculator_; }
+
+    // DEP/src/FrontierCostsManager.cpp:47-213.
+    bool assignCosts(std::vector<FrontierPtr> &frontier_list, std::vector<double> polygon_xy_min_max, Pose start_pose_w)
+    {
+        costCalculator_->reset();                               // :51
+        costCalculator_->setMaxArrivalInformation();            // :52
+        if (frontier_list.size() == 0) return false;            // :55-59
+        if (polygon_xy_min_max.size() <= 0) return false;       // :61-65
+        for (size_t i = 0; i < frontier_list.size(); ++i)       // :25-45,69-72
+            for (size_t j = i + 1; j < frontier_list.size(); ++j)
+                if (frontier_list[i] == frontier_list[j]) throw std::runtime_error("Duplicate frontiers found.");
+
+        const double dmax = std::numeric_limits<double>::max();
+        std::vector<FrontierPtr> live;
+        std::vector<uint8_t> black(frontier_list.size(), 0);
+        {
+            std::lock_guard<std::mutex> lock(blacklist_mutex_);
+            for (size_t i = 0; i < frontier_list.size(); ++i) {
+                auto &frontier = frontier_list[i];
+                if (frontier_blacklist_.count(frontier.get()) > 0) {   // :77-86
+                    frontier->setArrivalInformation(0.0); frontier->setGoalOrientation(0.0); frontier->setFisherInformation(0.0);
+                    frontier->setPathLength(dmax); frontier->setPathLengthInM(dmax); frontier->setWeightedCost(dmax);
+                    black[i] = 1;
+                    continue;
+                }
+                live.push_back(frontier);
+            }
+        }
+        costCalculator_->setArrivalInformationForFrontiers(live, polygon_xy_min_max);   // :96 batched
+        for (auto &frontier : live) {                                                    // :98-109
+            if (planner_) planner_(start_pose_w, frontier);
+            else costCalculator_->setPlanForFrontierEuclidean(start_pose_w, frontier);
+            costCalculator_->recomputeNormalizationFactors(frontier);                    // :118
+        }
+        // U1 + weighted cost on the GPU (:126-205)
+        const int32_t n = (int32_t)frontier_list.size();
+        std::vector<fs_record> rec(n);
+        std::vector<double> plen(n), phead(n), cost(n), au(n), du(n);
+        for (int32_t i = 0; i < n; ++i) {
+            auto &f = frontier_list[i];
+            rec[i] = fs_record{};
+            rec[i].arrival = (int32_t)f->getArrivalInformation();
+            rec[i].flags = (f->isAchievable() ? FS_FLAG_ACHIEVABLE : 0u);
+            plen[i] = f->getPathLength();
+            phead[i] = black[i] ? 0.0 : f->getPathHeading();
+        }
+        auto ctx = costCalculator_->context();
+        const int rc = fs_rank_candidates(ctx->get(), n, rec.data(), black.data(), plen.data(), phead.data(), alpha_, beta_, max_vx_, max_wx_,
+                                          cost.data(), au.data(), du.data(), nullptr);
+        if (rc == FS_E_RANGE) throw std::runtime_error("Cost out of bounds");   // :148-149,173-174
+        ctx->check(rc, "fs_rank_candidates");
+        for (int32_t i = 0; i < n; ++i) {
+            frontier_list[i]->setWeightedCost(cost[i]);
+            frontier_list[i]->setCost("arrival_gain_utility", au[i]);
+            frontier_list[i]->setCost("distance_utility", du[i]);
+        }
+        return true;
+    }
+
+    // :215-222
+    void setFrontierBlacklist(std::vector<FrontierPtr> &blacklist)
+    {
+        std::lock_guard<std::mutex> lock(blacklist_mutex_);
+        for (auto &frontier : blacklist) frontier_blacklist_[frontier.get()] = true;
+    }
+
+private:
+    double alpha_, beta_, max_vx_, max_wx_;
+    std::shared_ptr<FrontierCostCalculator> costCalculator_;
+    Planner planner_;
+    std::mutex blacklist_mutex_;
+    std::unordered_map<const Frontier *, bool> frontier_blacklist_;
+};
+
+// DEP/include/.../CostAssigner.hpp:43-59
+struct GetFrontierCostsRequest
+{
+    PoseStamped start_pose;
+    std::vector<FrontierPtr> frontier_list;
+    std::vector<std::vector<double>> every_frontier;
+    std::vector<FrontierPtr> prohibited_frontiers;
+};
+struct GetFrontierCostsResponse
+{
+    bool success = false;
+    std::vector<FrontierPtr> frontier_list;
+    std::vector<double> frontier_costs, frontier_distances, frontier_arrival_information, frontier_path_information;
+};
+
+class CostAssigner
+{
+public:
+    CostAssigner(std::shared_ptr<ScoringContext> ctx, std::shared_ptr<Costmap2D> costmap)
+        : costmap_(costmap), frontierCostsManager_(std::make_shared<FrontierCostsManager>(std::move(ctx), std::move(costmap))) {}
+
+    // DEP/src/CostAssigner.cpp:121-167 — polygon -> bbox [minx, miny, maxx, maxy]; empty polygon = whole map (with the
+    // reference's quirk of using getSizeInMeters, not origin + size, for the far corner).
+    bool updateBoundaryPolygon(const std::vector<Point> &explore_boundary)
+    {
+        std::vector<Point> pts = explore_boundary;
+        if (pts.empty()) {
+            Point t;
+            t.x = costmap_->getOriginX(); t.y = costmap_->getOriginY(); pts.push_back(t);
+            t.y = costmap_->getSizeInMetersY(); pts.push_back(t);
+            t.x = costmap_->getSizeInMetersX(); pts.push_back(t);
+            t.y = costmap_->getOriginY(); pts.push_back(t);
+        }
+        double mnx = std::numeric_limits<double>::infinity(), mny = mnx, mxx = -mnx, mxy = -mnx;
+        for (const auto &p : pts) {
+            // the reference stores the polygon as Point32 (float) before taking min/max
+            const double px = (double)(float)p.x, py = (double)(float)p.y;
+            mnx = std::min(mnx, px); mny = std::min(mny, py); mxx = std::max(mxx, px); mxy = std::max(mxy, py);
+        }
+        polygon_xy_min_max_ = {mnx, mny, mxx, mxy};
+        return true;
+    }
+
+    // DEP/src/CostAssigner.cpp:73-119
+    bool getFrontierCosts(std::shared_ptr<GetFrontierCostsRequest> requestData, std::shared_ptr<GetFrontierCostsResponse> resultData)
+    {
+        frontierCostsManager_->setFrontierBlacklist(requestData->prohibited_frontiers);
+        const bool costsResult = frontierCostsManager_->assignCosts(requestData->frontier_list, polygon_xy_min_max_, requestData->start_pose.pose);
+        if (costsResult == false) { resultData->success = false; return resultData->success; }
+        resultData->success = true;
+        resultData->frontier_list.clear(); resultData->frontier_costs.clear();
+        resultData->frontier_distances.clear(); resultData->frontier_arrival_information.clear();
+        for (auto &frontier : requestData->frontier_list) {
+            resultData->frontier_list.push_back(frontier);
+            resultData->frontier_costs.push_back(frontier->getWeightedCost());
+            resultData->frontier_distances.push_back(frontier->getPathLengthInM());
+            resultData->frontier_arrival_information.push_back(frontier->getArrivalInformation());
+        }
+        if (resultData->frontier_list != requestData->frontier_list) throw std::runtime_error("Lists are not SAME!");
+        return resultData->success;
+    }
+    std::shared_ptr<FrontierCostsManager> getCostManagerPtr() { return frontierCostsManager_; }
+
+private:
+    std::shared_ptr<Costmap2D> costmap_;
+    std::vector<double> polygon_xy_min_max_;
+    std::shared_ptr<FrontierCostsManager> frontierCostsManager_;
+};
+}  // namespace frontier_exploration
+
+namespace roadmap_explorer
+{
+using frontier_exploration::Point;
+using frontier_exploration::Pose;
+using frontier_exploration::ScoringContext;
+
+// FIP/include/.../FisherInfoManager.hpp:72-145
+class FisherInformationManager
+{
+public:
+    explicit FisherInformationManager(std::shared_ptr<ScoringContext> ctx, double fisher_information_threshold = 550.0)
+        : ctx_(std::move(ctx)), threshold_(fisher_information_threshold)
+    {
+        fs_fim_params p{14.0, 1.0};     // FisherInfoManager.cpp:64 radius; cone per DESIGN.md "Visibility"
+        ctx_->check(fs_set_fim_params(ctx_->get(), &p), "fs_set_fim_params");
+    }
+    // replaces the GetLandmarksInView service round-trip (FisherInfoManager.cpp:52-77): the whole cloud, staged once
+    void setLandmarks(const std::vector<float> &xyz) { ctx_->check(fs_upload_landmarks(ctx_->get(), xyz.data(), (int32_t)(xyz.size() / 3)), "fs_upload_landmarks"); }
+    void setVisibility(double max_dist, double max_angle)
+    {
+        fs_fim_params p{max_dist, max_angle};
+        ctx_->check(fs_set_fim_params(ctx_->get(), &p), "fs_set_fim_params");
+    }
+    // FisherInfoManager.hpp:94,96 — generateLookupTable / loadLookupTable (throws like the reference when the file is missing)
+    void generateLookupTable(float minX, float maxX, float minY, float maxY, float minZ, float maxZ)
+    {
+        const float b[6] = {minX, maxX, minY, maxY, minZ, maxZ};
+        ctx_->check(fs_lookup_generate(ctx_->get(), b), "fs_lookup_generate");
+    }
+    void generateLookupTable() { ctx_->check(fs_lookup_generate(ctx_->get(), nullptr), "fs_lookup_generate"); }
+    void saveLookupTable(const std::string &path) { ctx_->check(fs_lookup_save(ctx_->get(), path.c_str()), "fs_lookup_save"); }
+    void loadLookupTable(const std::string &path)
+    {
+        if (fs_lookup_load(ctx_->get(), path.c_str()) != FS_OK) throw std::runtime_error("Cannot load lookup table. Does it exist in the path?");
+    }
+    // FisherInfoManager.cpp:264-285 — plain table value, NaN when the key is absent
+    float getInformationFromLookup(const float landmark_camera_frame[3])
+    {
+        float v = 0;
+        ctx_->check(fs_lookup_query(ctx_->get(), landmark_camera_frame, &v), "fs_lookup_query");
+        return v;
+    }
+    // FisherInfoManager.cpp:39-115
+    bool isPoseSafe(Pose &given_pose, bool /*exhaustiveSearch*/, float &information)
+    {
+        const double pose7[7] = {given_pose.position.x, given_pose.position.y, given_pose.position.z,
+                                 given_pose.orientation.x, given_pose.orientation.y, given_pose.orientation.z, given_pose.orientation.w};
+        float info = 0;
+        if (fs_score_fim(ctx_->get(), 1, pose7, &info, nullptr, nullptr, nullptr, nullptr, nullptr) != FS_OK) return false;   // service failure -> false (:52-57,73-77)
+        information = info;
+        return info > threshold_;                                                                                                 // :112-114
+    }
+    // FisherInfoManager.cpp:31-37
+    bool isPoseSafe(Point point_from, Point point_to, bool exhaustiveSearch)
+    {
+        Pose relative_pose;
+        frontier_exploration::getRelativePoseGivenTwoPoints(point_from, point_to, relative_pose);
+        float information;
+        return isPoseSafe(relative_pose, exhaustiveSearch, information);
+    }
+    // batch form used by the scorer: one call for many poses
+    void poseInformation(const std::vector<Pose> &poses, std::vector<float> &information)
+    {
+        std::vector<double> p7(poses.size() * 7);
+        for (size_t i = 0; i < poses.size(); ++i) {
+            const Pose &p = poses[i];
+            const double v[7] = {p.position.x, p.position.y, p.position.z, p.orientation.x, p.orientation.y, p.orientation.z, p.orientation.w};
+            for (int k = 0; k < 7; ++k) p7[7 * i + k] = v[k];
+        }
+        information.assign(poses.size(), 0.0f);
+        ctx_->check(fs_score_fim(ctx_->get(), (int32_t)poses.size(), p7.data(), information.data(), nullptr, nullptr, nullptr, nullptr, nullptr), "fs_score_fim");
+    }
+
+private:
+    std::shared_ptr<ScoringContext> ctx_;
+    double threshold_;
+};
+}  // namespace roadmap_explorer
+
+#endif

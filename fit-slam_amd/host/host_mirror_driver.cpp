@@ -1,0 +1,115 @@
+// host_mirror_driver.cpp — exercises the C++ host-side mirror (frontier_scoring.hpp) on the GPU.
+// tests/test_host_mirror.py writes a workload file, runs this program and compares its output with the
+// oracle.  Usage: host_mirror_driver <workload.bin> <result.bin>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "frontier_scoring.hpp"
+
+using namespace frontier_exploration;
+
+template <typename T>
+static void rd(FILE *f, T *p, size_t n)
+{
+    if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+}
+
+static int expect_throw(const char *what, const std::function<void()> &fn)
+{
+    try { fn(); } catch (const std::exception &e) { printf("CHECK %s: threw (%s)\n", what, e.what()); return 0; }
+    printf("CHECK %s: DID NOT THROW\n", what);
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { fprintf(stderr, "usage: %s workload.bin result.bin\n", argv[0]); return 2; }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) { perror("workload"); return 2; }
+    int32_t nx, ny, n, m;
+    double res, ox, oy, start[3], poly[4];
+    rd(f, &nx, 1); rd(f, &ny, 1); rd(f, &res, 1); rd(f, &ox, 1); rd(f, &oy, 1);
+    auto costmap = std::make_shared<Costmap2D>((unsigned)nx, (unsigned)ny, res, ox, oy, 0);
+    rd(f, costmap->getCharMap(), (size_t)nx * ny);
+    rd(f, &n, 1);
+    std::vector<double> goals(2 * (size_t)n);
+    std::vector<int32_t> sizes(n);
+    std::vector<uint8_t> black(n);
+    rd(f, goals.data(), goals.size()); rd(f, sizes.data(), n); rd(f, black.data(), n);
+    rd(f, &m, 1);
+    std::vector<float> lm(3 * (size_t)m);
+    rd(f, lm.data(), lm.size());
+    rd(f, start, 3); rd(f, poly, 4);
+    fclose(f);
+
+    int failures = 0;
+    auto ctx = std::make_shared<ScoringContext>(0);
+    CostAssigner assigner(ctx, costmap);
+    std::vector<Point> boundary(4);
+    boundary[0].x = poly[0]; boundary[0].y = poly[1]; boundary[1].x = poly[0]; boundary[1].y = poly[3];
+    boundary[2].x = poly[2]; boundary[2].y = poly[3]; boundary[3].x = poly[2]; boundary[3].y = poly[1];
+    assigner.updateBoundaryPolygon(boundary);
+
+    auto req = std::make_shared<GetFrontierCostsRequest>();
+    auto res_ = std::make_shared<GetFrontierCostsResponse>();
+    req->start_pose.pose.position.x = start[0];
+    req->start_pose.pose.position.y = start[1];
+    req->start_pose.pose.orientation = orientationAroundZAxis(start[2]);
+    for (int32_t i = 0; i < n; ++i) {
+        auto fr = std::make_shared<Frontier>();
+        fr->setUID((size_t)i + 1); fr->setSize(sizes[i]); fr->setGoalPoint(goals[2 * i], goals[2 * i + 1]);
+        req->frontier_list.push_back(fr);
+        if (black[i]) req->prohibited_frontiers.push_back(fr);
+    }
+    const bool ok = assigner.getFrontierCosts(req, res_);
+    printf("getFrontierCosts -> %d, %zu frontiers\n", (int)ok, res_->frontier_list.size());
+    if (!ok || !res_->success) ++failures;
+
+    // Fisher information at (goal, best yaw), built like isPoseSafe(Point, Point)
+    roadmap_explorer::FisherInformationManager fim(ctx);
+    failures += expect_throw("loadLookupTable(missing file)", [&] { fim.loadLookupTable("/nonexistent/fisher_information_lookup_table.dat"); });
+    fim.generateLookupTable();
+    fim.setLandmarks(lm);
+    std::vector<Pose> poses(n);
+    for (int32_t i = 0; i < n; ++i) {
+        poses[i].position = req->frontier_list[i]->getGoalPoint();
+        poses[i].orientation = req->frontier_list[i]->getGoalOrientation();
+    }
+    std::vector<float> info;
+    fim.poseInformation(poses, info);
+    float single = -1;
+    const bool safe = fim.isPoseSafe(poses[0], false, single);
+    printf("isPoseSafe(pose0) -> %d, information %.6f (batch %.6f)\n", (int)safe, single, info[0]);
+    if (single != info[0] || safe != (single > 550.0f)) ++failures;
+
+    // error behaviour of the reference interface
+    failures += expect_throw("Frontier getter on unset field", [] { Frontier fr; (void)fr.getArrivalInformation(); });
+    failures += expect_throw("duplicate frontiers", [&] {
+        auto r2 = std::make_shared<GetFrontierCostsRequest>(*req);
+        r2->frontier_list.push_back(r2->frontier_list[0]);
+        auto o2 = std::make_shared<GetFrontierCostsResponse>();
+        assigner.getFrontierCosts(r2, o2);
+    });
+    {
+        auto r3 = std::make_shared<GetFrontierCostsRequest>();
+        auto o3 = std::make_shared<GetFrontierCostsResponse>();
+        const bool empty_ok = assigner.getFrontierCosts(r3, o3);
+        printf("CHECK empty frontier list: returned %d\n", (int)empty_ok);
+        if (empty_ok || o3->success) ++failures;
+    }
+
+    FILE *o = fopen(argv[2], "wb");
+    if (!o) { perror("result"); return 2; }
+    for (int32_t i = 0; i < n; ++i) {
+        const auto &fr = res_->frontier_list[i];
+        const double row[8] = {res_->frontier_arrival_information[i], fr->getGoalYaw(), (double)fr->isAchievable(),
+                               res_->frontier_costs[i], fr->getCost("arrival_gain_utility"), fr->getCost("distance_utility"),
+                               res_->frontier_distances[i], (double)info[i]};
+        fwrite(row, sizeof(double), 8, o);
+    }
+    fclose(o);
+    printf("failures: %d\n", failures);
+    return failures ? 1 : 0;
+}
