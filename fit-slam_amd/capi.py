@@ -20,7 +20,7 @@ FS_MAX_ELEV = 16
 # every symbol include/fitslam_frontier.h declares
 EXPORTED_SYMBOLS = [
     "fs_abi_version", "fs_ctx_create", "fs_ctx_destroy", "fs_last_error", "fs_synchronize",
-    "fs_enable_kernel_timing", "fs_kernel_time",
+    "fs_enable_kernel_timing", "fs_kernel_time", "fs_set_option", "fs_get_counter",
     "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_max_arrival", "fs_set_arrival_limits",
     "fs_score_arrival",
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
@@ -75,6 +75,8 @@ def load_library(build: bool = True):
     L.fs_synchronize.argtypes = [vp]
     L.fs_enable_kernel_timing.argtypes = [vp, C.c_int]
     L.fs_kernel_time.argtypes = [vp, C.c_int, C.POINTER(dbl), C.POINTER(i64)]
+    L.fs_set_option.argtypes = [vp, C.c_char_p, dbl]
+    L.fs_get_counter.argtypes = [vp, C.c_int, C.POINTER(i64), C.c_int]
     L.fs_set_ray_params.argtypes = [vp, C.POINTER(RayParamsC)]
     L.fs_ray_fan_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.fs_upload_grid.argtypes = [vp, vp, i32, i32, i32, C.POINTER(dbl * 3), dbl]
@@ -147,6 +149,14 @@ class FrontierScorer:
         ms, cnt = C.c_double(), C.c_int64()
         self._check(self._L.fs_kernel_time(self._h, kind, C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def set_option(self, key: str, value: float):
+        self._check(self._L.fs_set_option(self._h, key.encode(), float(value)))
+
+    def get_counter(self, which: int, reset: bool = False) -> int:
+        v = C.c_int64()
+        self._check(self._L.fs_get_counter(self._h, int(which), C.byref(v), 1 if reset else 0))
+        return v.value
 
     # -- arrival information
     def set_ray_params(self, max_camera_depth=2.0, delta_theta=0.10, camera_fov=1.04, robot_radius=0.60,

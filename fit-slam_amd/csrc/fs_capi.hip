@@ -73,8 +73,10 @@ struct fs_ctx {
 
     // landmarks
     bool have_lm = false;
-    int32_t m = 0, m_padded = 0;
-    DevBuf<float> d_lx, d_ly, d_lz;
+    int32_t m = 0, n_chunks = 0;
+    DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
+    bool opt_cull = true;
+    DevBuf<unsigned long long> d_counters;
 
     // lookup table
     bool have_table = false;
@@ -357,27 +359,38 @@ int fill_ray_args(fs_ctx *c, FsRayArgs &a)
 int fill_fim_args(fs_ctx *c, FsFimArgs &a)
 {
     a.lx = c->d_lx.p; a.ly = c->d_ly.p; a.lz = c->d_lz.p;
-    a.m_padded = c->m_padded;
+    a.spheres = c->d_spheres.p;
+    a.n_chunks = c->n_chunks;
+    a.cull = c->opt_cull ? 1 : 0;
     a.table = c->d_table.p;
     a.jx0 = c->jx0; a.jy0 = c->jy0; a.jz0 = c->jz0;
     a.tx = c->tx; a.ty = c->ty; a.tz = c->tz;
     a.inv_step = 1 / (double)kStepMax;
+    a.inv_step_f = (float)a.inv_step;
     a.factor = c->d_factor.p;
     a.maxd2 = (float)(c->fp.max_dist * c->fp.max_dist);
+    a.max_dist_f = (float)c->fp.max_dist * 1.0001f + 1.0e-3f;      // culling reach, rounded outwards
     if (c->fp.max_angle >= M_PI) {
-        a.cone_mode = 0; a.cos2 = 0.0f;
+        a.cone_mode = 0; a.cos2 = 0.0f; a.cos_a = -1.0f; a.sin_a = 0.0f;
     } else {
         const float cs = (float)std::cos(c->fp.max_angle);
         a.cos2 = cs * cs;
         a.cone_mode = (cs >= 0.0f) ? 1 : 2;
+        // chunk culling uses a slightly wider cone (alpha + 1e-3 rad) than the exact per-landmark predicate
+        a.cos_a = (float)std::cos(c->fp.max_angle + 1.0e-3);
+        a.sin_a = (float)std::sin(c->fp.max_angle + 1.0e-3);
+        if (c->fp.max_angle + 1.0e-3 >= M_PI / 2) a.cone_mode = (a.cone_mode == 1) ? 3 : 2;   // 3: exact predicate of mode 1, no cone culling
     }
-    // LDS table: enough for every landmark to sit in its own voxel when the cloud is small,
-    // otherwise 2^15 slots (128 KiB of the CU's 160 KiB); fuller candidates take the HBM-table pass
+    // tier 1: 2^14 LDS slots (64 KiB, two 512-thread workgroups per CU) or fewer for small clouds;
+    // tier 2: 2^15 slots (128 KiB, one 1024-thread workgroup per CU); tier 3: HBM
     int bits = 10;
-    while (bits < 15 && (1 << bits) < 2 * c->m) ++bits;
+    while (bits < 14 && (1 << bits) < 2 * c->m) ++bits;
     a.hash_bits = bits;
+    a.hash_bits2 = ((1 << bits) < 2 * c->m) ? 15 : bits;
+    a.fail_code1 = (a.hash_bits2 > a.hash_bits) ? 1u : 2u;
     a.gtable = c->d_gtable.p;
     a.ghash_bits = c->ghash_bits;
+    a.counters = c->d_counters.p;
     return FS_OK;
 }
 
@@ -433,7 +446,7 @@ void fs_ctx_destroy(fs_ctx *c)
     for (auto &t : c->launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     c->d_dir.release(); c->d_yawR.release(); c->d_cells.release();
-    c->d_lx.release(); c->d_ly.release(); c->d_lz.release();
+    c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
     c->d_goal.release(); c->d_yaw.release(); c->d_len.release(); c->d_head.release();
     c->d_cost.release(); c->d_au.release(); c->d_du.release(); c->d_sums.release();
@@ -695,22 +708,110 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
 {
     if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    const int32_t mp = std::max<int32_t>(FS_LM_PAD, (m + FS_LM_PAD - 1) / FS_LM_PAD * FS_LM_PAD);
+    if (m > 65535 * FS_CHUNK) return fail(c, FS_E_INVALID, "at most %d landmarks per context", 65535 * FS_CHUNK);
+    // Morton order (10 bits per axis inside the cloud's bounding box) so that 64 consecutive landmarks
+    // are spatial neighbours; non-finite points sort last.
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int32_t i = 0; i < m; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float v = xyz[3 * i + a];
+            if (std::isfinite(v)) { lo[a] = std::min(lo[a], (double)v); hi[a] = std::max(hi[a], (double)v); }
+        }
+    auto spread = [](uint32_t v) {
+        v &= 0x3ffu;
+        v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu;
+        v = (v | (v << 4)) & 0x030c30c3u;  v = (v | (v << 2)) & 0x09249249u;
+        return v;
+    };
+    std::vector<std::pair<uint32_t, int32_t>> order((size_t)m);
+    for (int32_t i = 0; i < m; ++i) {
+        uint32_t code = 0xffffffffu;
+        const float *p = xyz + 3 * (size_t)i;
+        if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                const double ext = hi[a] - lo[a];
+                q[a] = ext > 0 ? (uint32_t)std::min(1023.0, (p[a] - lo[a]) / ext * 1024.0) : 0u;
+            }
+            code = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        order[i] = {code, i};
+    }
+    std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    const int32_t n_chunks = std::max<int32_t>(1, (m + FS_CHUNK - 1) / FS_CHUNK);
+    const size_t mp = (size_t)n_chunks * FS_CHUNK;
     // SoA + far-away sentinels in the padding: (1e18)^2 is finite in fp32 and beyond any max_dist^2
-    std::vector<float> x((size_t)mp, 1.0e18f), y((size_t)mp, 1.0e18f), z((size_t)mp, 1.0e18f);
-    for (int32_t i = 0; i < m; ++i) { x[i] = xyz[3 * i]; y[i] = xyz[3 * i + 1]; z[i] = xyz[3 * i + 2]; }
+    std::vector<float> x(mp, 1.0e18f), y(mp, 1.0e18f), z(mp, 1.0e18f), sph((size_t)n_chunks * 4, 0.0f);
+    for (int32_t i = 0; i < m; ++i) {
+        const float *p = xyz + 3 * (size_t)order[i].second;
+        x[i] = p[0]; y[i] = p[1]; z[i] = p[2];
+    }
+    for (int32_t ch = 0; ch < n_chunks; ++ch) {
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        int cnt = 0;
+        for (int k = 0; k < FS_CHUNK; ++k) {
+            const size_t i = (size_t)ch * FS_CHUNK + k;
+            if (i >= (size_t)m || !std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i])) continue;
+            const double p[3] = {x[i], y[i], z[i]};
+            for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], p[a]); bhi[a] = std::max(bhi[a], p[a]); }
+            ++cnt;
+        }
+        float *s4 = &sph[4 * (size_t)ch];
+        if (cnt == 0) { s4[0] = s4[1] = s4[2] = 0.0f; s4[3] = -1.0e30f; continue; }   // never accepted, holds nothing visible
+        const float ctr[3] = {(float)(0.5 * (blo[0] + bhi[0])), (float)(0.5 * (blo[1] + bhi[1])), (float)(0.5 * (blo[2] + bhi[2]))};
+        double r2 = 0.0;
+        for (int k = 0; k < FS_CHUNK; ++k) {
+            const size_t i = (size_t)ch * FS_CHUNK + k;
+            if (i >= (size_t)m || !std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i])) continue;
+            const double dx = (double)x[i] - ctr[0], dy = (double)y[i] - ctr[1], dz = (double)z[i] - ctr[2];
+            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
+        s4[0] = ctr[0]; s4[1] = ctr[1]; s4[2] = ctr[2];
+        s4[3] = (float)(std::sqrt(r2) * 1.01 + 2.0e-3);          // safety margin: culling must never drop a visible landmark
+    }
     FS_HIP(c, c->d_lx.ensure(mp)); FS_HIP(c, c->d_ly.ensure(mp)); FS_HIP(c, c->d_lz.ensure(mp));
+    FS_HIP(c, c->d_spheres.ensure(sph.size()));
     FS_HIP(c, hipMemcpyAsync(c->d_lx.p, x.data(), sizeof(float) * mp, hipMemcpyHostToDevice, c->stream));
     FS_HIP(c, hipMemcpyAsync(c->d_ly.p, y.data(), sizeof(float) * mp, hipMemcpyHostToDevice, c->stream));
     FS_HIP(c, hipMemcpyAsync(c->d_lz.p, z.data(), sizeof(float) * mp, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_spheres.p, sph.data(), sizeof(float) * sph.size(), hipMemcpyHostToDevice, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
-    c->m = m; c->m_padded = mp;
-    // HBM hash tables for the overflow pass: one per pool workgroup, 2x the landmark count
+    c->m = m; c->n_chunks = n_chunks;
+    // HBM hash tables for tier 3: one per pool workgroup, 2x the landmark count
     int gb = 12;
     while ((1ll << gb) < 2ll * std::max(m, 1)) ++gb;
     c->ghash_bits = gb;
     FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
+    if (!c->d_counters.p) {
+        FS_HIP(c, c->d_counters.ensure(8));
+        FS_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        FS_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->have_lm = true;
+    return FS_OK;
+}
+
+int fs_set_option(fs_ctx *c, const char *key, double value)
+{
+    if (!c || !key) return FS_E_INVALID;
+    if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
+    return fail(c, FS_E_INVALID, "unknown option %s", key);
+}
+
+int fs_get_counter(fs_ctx *c, int which, int64_t *value, int reset)
+{
+    if (!c || !value || which < 0 || which > 7) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    *value = 0;
+    if (!c->d_counters.p) return FS_OK;
+    unsigned long long v = 0;
+    FS_HIP(c, hipMemcpyAsync(&v, c->d_counters.p + which, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    *value = (int64_t)v;
+    if (reset) {
+        FS_HIP(c, hipMemsetAsync(c->d_counters.p + which, 0, sizeof v, c->stream));
+        FS_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return FS_OK;
 }
 
@@ -804,8 +905,8 @@ static int run_fim(fs_ctx *c, FsFimArgs &a)
         ScopedTimer t(c, 1);
         FS_HIP(c, fs_launch_fim(a, c->stream));
     }
-    if (a.hash_bits < 20 && (1 << a.hash_bits) < 2 * c->m) {
-        // the LDS table can fill up only when the cloud has more landmarks than half its slots
+    {
+        // tiers 2 and 3 exit at once unless the previous tier flagged a candidate (device-side counters)
         ScopedTimer t(c, 2);
         FS_HIP(c, fs_launch_fim_overflow(a, fs_ctx::kPool, c->stream));
     }
@@ -831,6 +932,13 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
     FsFimArgs a{};
     fill_fim_args(c, a);
     a.n = n; a.Rt = c->d_Rt.p;
+    // chunk culling reasons in world space and needs R orthonormal: a non-unit quaternion (which the
+    // reference would feed to Eigen unnormalised) switches this call to the brute-force scan
+    for (int32_t i = 0; i < n && a.cull; ++i) {
+        const double *q = pose7 + 7 * (size_t)i + 3;
+        const double nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        if (!(std::fabs(nn - 1.0) <= 1.0e-4)) a.cull = 0;
+    }
     a.fim21 = fim21 ? c->d_fim21.p : nullptr;
     rc = run_fim(c, a);
     if (rc) return rc;

@@ -4,23 +4,36 @@
 // (FIP/src/fisher_information/FisherInfoManager.cpp:83-100,287-324) plus the per-landmark Jacobian/FIM
 // of FisherInformationHelpers.cpp:71-123, batched over candidate poses.
 //
-// Mapping: one workgroup per candidate.  The landmark cloud (SoA fp32, staged once to HBM, L2-resident
-// at these sizes) is streamed with 16-byte loads, four landmarks per lane per step.  For every
-// landmark: p = R^T (w - t) in fp32 with explicit fma order, the visibility predicate (range + cone,
-// multiplications and compares only), the voxel lattice index in fp64 (round(p * 1/0.3f), identical to
-// getVoxelCoordinate, FisherInfoManager.hpp:108-123).  The reference's per-voxel bookkeeping
-// (pointCount / version, :296-304) becomes an LDS hash table keyed by the dense lattice index:
-// the returning LDS atomic that bumps the voxel's count yields the landmark's rank k in its voxel,
-// hence its crowding factor exp(1 - k^0.8) (table, FisherInfoManager.hpp:102-106) — the same multiset
-// of (info_v, k) terms the reference accumulates sequentially.  The unit-weight 6x6 FIM uses the block
-// form F(p) = [[P/n^2, -S/n^2],[S/n^2, P]] (17 independent sums).  Sums are reduced with wave shuffles,
-// then across waves through LDS; lane 0 finishes trace and log det (Cholesky, fp64).
-// This is a scan + scatter-count: no dense contraction, so no MFMA.
+// Data: the landmark cloud is staged once (fs_upload_landmarks) in Morton order as SoA fp32 and cut
+// into chunks of 64 consecutive landmarks, each with a bounding sphere.  One workgroup scores one
+// candidate:
+//   1. cull   — every lane tests chunk spheres against the visibility volume (range sphere + cone,
+//               conservative); accepted chunk ids go to an LDS list.  Only a few per cent of a 512^3
+//               map's cloud survives, so the per-landmark work drops by an order of magnitude while the
+//               visible set stays exactly the brute-force one (the exact predicate is re-evaluated
+//               per landmark).
+//   2. test   — one wave per accepted chunk: coalesced 256-B loads, p = R^T (w - t) in fp32 with the
+//               specified fma order, range + cone predicate (multiplications and compares only).
+//   3. compact— visible lanes push p into the wave's LDS queue (ballot + mbcnt); whenever 64 are queued
+//               the whole wave runs the expensive part at full lane utilisation.
+//   4. score  — voxel lattice index (fp32 fast path, exact fp64 re-evaluation only next to a rounding
+//               boundary: identical to getVoxelCoordinate, FisherInfoManager.hpp:108-123), dense-table
+//               value, and the reference's per-voxel pointCount bookkeeping (:296-304) as an LDS hash
+//               table keyed by the lattice index: the returning LDS atomic that bumps the voxel's
+//               count is the landmark's rank k in its voxel -> crowding factor exp(1 - k^0.8)
+//               (FisherInfoManager.hpp:102-106).  Same multiset of (info_v, k) terms as the reference's
+//               sequential loop.  Unit-weight 6x6 FIM via the block form [[P/n^2,-S/n^2],[S/n^2,P]].
+//   5. reduce — wave shuffles, LDS across waves, fp64 per quantity; fs_fim_finish_kernel assembles F,
+//               trace and the Cholesky log det.
+// Hash tables are tiered: 2^14 LDS slots per 512-thread workgroup (two workgroups per CU); candidates
+// with more distinct voxels are flagged and re-scored with 2^15 slots / 1024 threads, then with a table
+// in HBM.  Scan + scatter-count has no dense contraction: no MFMA.
 #include "fs_internal.h"
 
-#define FS_FIM_THREADS 1024
-#define FS_FIM_WAVES (FS_FIM_THREADS / 64)
-#define FS_NACC 18     // info, 15 FIM block sums, n_visible, n_voxels
+#define FS_NACC 18       // info, 15 FIM block sums, n_visible, n_voxels
+#define FS_QCAP 128      // per-wave compaction queue (<= 63 left over + 64 new)
+#define FS_LIST_SEG 512  // accepted-chunk list segment (chunks culled per pass)
+#define FS_MAX_PROBE 96  // LDS tiers give up (-> next tier) after this many probes
 
 namespace {
 
@@ -38,14 +51,14 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
 }
 
 // find-or-insert `key` and bump its count; returns the landmark's rank in the voxel (1-based),
-// 0 if the table is full.  *is_new is set when this call created the voxel entry.
-__device__ __forceinline__ uint32_t table_bump(uint32_t *table, int bits, uint32_t key, bool &is_new)
+// 0 if no slot was found within max_probe.  is_new is set when this call created the voxel entry.
+__device__ __forceinline__ uint32_t table_bump(uint32_t *table, int bits, uint32_t key, uint32_t max_probe, bool &is_new)
 {
     const uint32_t mask = (1u << bits) - 1u;
     const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
     uint32_t h = hash_key(key, bits);
     is_new = false;
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
+    for (uint32_t probe = 0; probe < max_probe; ++probe) {
         uint32_t cur = table[h];
         if (cur == 0u) {
             const uint32_t prev = atomicCAS(&table[h], 0u, tag | 1u);
@@ -62,33 +75,47 @@ __device__ __forceinline__ uint32_t table_bump(uint32_t *table, int bits, uint32
     return 0u;
 }
 
-__device__ __forceinline__ void visible_landmark(const FsFimArgs &a, uint32_t *table, int bits,
-                                                 float px, float py, float pz, float n2,
-                                                 Acc &acc, bool &overflow)
+// round(x * (1 / corrected_step)) of getVoxelCoordinate (FisherInfoManager.hpp:119-121), exactly.
+// The fp32 product is within |r| * 1.3e-7 of the fp64 one (|r| < 2^10 checked), so away from a .5 boundary
+// the fp32 nearest integer equals the fp64 half-away-from-zero result; next to one, evaluate the fp64 expression.
+__device__ __forceinline__ int voxel_index(float p, double inv_step, float inv_step_f)
+{
+    const float r = p * inv_step_f;
+    const float rn = rintf(r);
+    const float frac = fabsf(r - rn);
+    if (frac < 0.49f && fabsf(r) < 1024.0f) return (int)rn;
+    return (int)round((double)p * inv_step);
+}
+
+__device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *table, int bits, uint32_t max_probe,
+                                              float px, float py, float pz, Acc &acc, bool &overflow)
 {
     acc.nvis += 1;
+    // dense-table lookup first: its latency overlaps the FIM arithmetic below
+    const int jx = voxel_index(px, a.inv_step, a.inv_step_f) - a.jx0;
+    const int jy = voxel_index(py, a.inv_step, a.inv_step_f) - a.jy0;
+    const int jz = voxel_index(pz, a.inv_step, a.inv_step_f) - a.jz0;
+    const bool in_table = (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
+    const uint32_t key = ((uint32_t)jx * (uint32_t)a.ty + (uint32_t)jy) * (uint32_t)a.tz + (uint32_t)jz;
+    float info_v = __builtin_nanf("");
+    if (in_table) info_v = a.table[key];                     // key miss -> NaN -> skipped (:90-94)
+
     // unit-weight FIM block sums, F(p) = [[P/n^2, -S/n^2],[S/n^2, P]].  P's diagonal is
-    // formed as a sum of squares (1 - ux^2 = uy^2 + uz^2) so that no per-landmark cancellation occurs.
-    // The zero vector has no Jacobian.
+    // formed as a sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector
+    // has no Jacobian.
+    const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
     if (n2 > 0.0f) {
         const float q = 1.0f / n2;
         const float qx = px * q, qy = py * q, qz = pz * q;
         const float xx = px * qx, yy = py * qy, zz = pz * qz;
-        const float a[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
+        const float v[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { acc.A[i] += a[i]; acc.B[i] += a[i] * q; }
+        for (int i = 0; i < 6; ++i) { acc.A[i] += v[i]; acc.B[i] += v[i] * q; }
         acc.s[0] += qx; acc.s[1] += qy; acc.s[2] += qz;
     }
-    // getVoxelCoordinate: round(x * (1 / corrected_step)) in double, FisherInfoManager.hpp:119-121
-    const int jx = (int)round((double)px * a.inv_step) - a.jx0;
-    const int jy = (int)round((double)py * a.inv_step) - a.jy0;
-    const int jz = (int)round((double)pz * a.inv_step) - a.jz0;
-    if ((unsigned)jx >= (unsigned)a.tx || (unsigned)jy >= (unsigned)a.ty || (unsigned)jz >= (unsigned)a.tz) return;   // key miss -> NaN -> skipped (:90-94)
-    const uint32_t key = ((uint32_t)jx * (uint32_t)a.ty + (uint32_t)jy) * (uint32_t)a.tz + (uint32_t)jz;
-    const float info_v = a.table[key];
     if (info_v != info_v) return;                            // absent lattice point
     bool is_new;
-    const uint32_t rank = table_bump(table, bits, key, is_new);
+    const uint32_t rank = table_bump(table, bits, key, max_probe, is_new);
     if (rank == 0u) { overflow = true; return; }
     if (is_new) acc.nvox += 1;                               // occupied_voxel_count_++ (:304)
     const float fac = rank < FS_FACTOR_N ? a.factor[rank] : 0.0f;
@@ -97,12 +124,26 @@ __device__ __forceinline__ void visible_landmark(const FsFimArgs &a, uint32_t *t
     acc.info += info_v * fac;
 }
 
-template <bool GLOBAL_TABLE>
-__device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_t *table, int bits, float *red)
+// dynamic-LDS carve-up of one workgroup: [per-wave queues][accepted-chunk list][hash table]
+template <int THREADS>
+struct Lds {
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr size_t fixed_words = (size_t)WAVES * 3 * FS_QCAP + FS_LIST_SEG / 2;
+    static __device__ __forceinline__ float *queue(uint32_t *base, int wave) { return reinterpret_cast<float *>(base) + wave * (3 * FS_QCAP); }
+    static __device__ __forceinline__ uint16_t *list(uint32_t *base) { return reinterpret_cast<uint16_t *>(base + WAVES * 3 * FS_QCAP); }
+    static __device__ __forceinline__ uint32_t *table(uint32_t *base) { return base + fixed_words; }
+};
+
+template <int THREADS, bool GLOBAL_TABLE>
+__device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_t *lds, uint32_t *table, int bits,
+                                              uint32_t fail_code)
 {
+    constexpr int WAVES = THREADS / 64;
+    const uint32_t max_probe = GLOBAL_TABLE ? (1u << bits) : FS_MAX_PROBE;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    __shared__ int sh_overflow;
+    __shared__ int sh_overflow, sh_count, sh_tested;
+    __shared__ float sh_red[WAVES * FS_NACC];
 
     // ---- pose
     float R[9], t[3];
@@ -121,9 +162,13 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
 
     // ---- clear the hash table
     const uint32_t slots = 1u << bits;
-    for (uint32_t i = tid; i < slots; i += FS_FIM_THREADS) table[i] = 0u;
-    if (tid == 0) sh_overflow = 0;
-    __syncthreads();
+    if (GLOBAL_TABLE) {
+        for (uint32_t i = tid; i < slots; i += THREADS) table[i] = 0u;
+    } else {
+        uint4 *t4 = reinterpret_cast<uint4 *>(table);
+        for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid == 0) { sh_overflow = 0; sh_tested = 0; }
 
     Acc acc;
     acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
@@ -133,32 +178,82 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     for (int i = 0; i < 3; ++i) acc.s[i] = 0.f;
     bool overflow = false;
 
-    const float4 *__restrict__ X = reinterpret_cast<const float4 *>(a.lx);
-    const float4 *__restrict__ Y = reinterpret_cast<const float4 *>(a.ly);
-    const float4 *__restrict__ Z = reinterpret_cast<const float4 *>(a.lz);
-    const int n4 = a.m_padded >> 2;
-    for (int i4 = tid; i4 < n4; i4 += FS_FIM_THREADS) {
-        const float4 x4 = X[i4], y4 = Y[i4], z4 = Z[i4];
-        const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
-        const float ys[4] = {y4.x, y4.y, y4.z, y4.w};
-        const float zs[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
+    float *qx = Lds<THREADS>::queue(lds, wave), *qy = qx + FS_QCAP, *qz = qy + FS_QCAP;
+    uint16_t *list = Lds<THREADS>::list(lds);
+    int qcount = 0;                                            // wave-uniform
+    int tested = 0;
+
+    // cone axis in the world frame = first column of R^T's row 0, i.e. px = ax*dx + ay*dy + az*dz
+    const float ax = R[0], ay = R[3], az = R[6];
+    const float4 *__restrict__ spheres = reinterpret_cast<const float4 *>(a.spheres);
+
+    for (int seg = 0; seg < a.n_chunks; seg += FS_LIST_SEG) {
+        if (tid == 0) sh_count = 0;
+        __syncthreads();
+        // ---- 1. cull: one chunk sphere per lane (conservative: s.w carries a safety margin)
+        const int seg_end = min(a.n_chunks, seg + FS_LIST_SEG);
+        for (int j = seg + tid; j < seg_end; j += THREADS) {
+            bool keep = true;
+            if (a.cull) {
+                const float4 s = spheres[j];
+                const float dx = s.x - t[0], dy = s.y - t[1], dz = s.z - t[2];
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float reach = a.max_dist_f + s.w;
+                keep = d2 <= reach * reach;
+                if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
+                    // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|)
+                    const float dist = sqrtf(d2);
+                    const float sb = s.w / dist;                           // < 1 here
+                    const float cb = sqrtf(fmaxf(0.0f, 1.0f - sb * sb));
+                    const float cab = a.cos_a * cb - a.sin_a * sb;          // cos(alpha + beta)
+                    const float dot = dx * ax + dy * ay + dz * az;
+                    keep = dot >= dist * cab - 1.0e-4f * dist - 1.0e-4f;
+                }
+            }
+            if (keep) {
+                const int pos = atomicAdd(&sh_count, 1);
+                list[pos] = (uint16_t)(j - seg);
+            }
+        }
+        __syncthreads();
+        const int count = sh_count;
+        if (tid == 0) tested += count;
+        // ---- 2./3./4. one wave per accepted chunk
+        for (int i = wave; i < count; i += WAVES) {
+            const int chunk = seg + (int)list[i];
+            const int l = chunk * 64 + lane;
+            const float wx = a.lx[l], wy = a.ly[l], wz = a.lz[l];
             // p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
-            const float dx = xs[k] - t[0], dy = ys[k] - t[1], dz = zs[k] - t[2];
+            const float dx = wx - t[0], dy = wy - t[1], dz = wz - t[2];
             const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
             const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
             const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
             const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
             bool vis = (n2 <= a.maxd2);
-            if (a.cone_mode == 1) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
+            if (a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
             else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px * px <= a.cos2 * n2));
-            if (vis) visible_landmark(a, table, bits, px, py, pz, n2, acc, overflow);
+            const unsigned long long m = __ballot(vis);
+            if (m != 0ull) {
+                if (vis) {
+                    const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    qx[pos] = px; qy[pos] = py; qz[pos] = pz;
+                }
+                qcount += __popcll(m);
+                if (qcount >= 64) {
+                    qcount -= 64;                                  // take the newest 64: the remainder stays in place
+                    const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
+                    score_visible(a, table, bits, max_probe, ex, ey, ez, acc, overflow);
+                }
+            }
         }
+        __syncthreads();                                           // list / sh_count are reused by the next segment
     }
+    // flush the queue remainder
+    if (lane < qcount) score_visible(a, table, bits, max_probe, qx[lane], qy[lane], qz[lane], acc, overflow);
     if (overflow) sh_overflow = 1;
+    if (tid == 0) sh_tested = tested;
 
-    // ---- reduce: wave shuffles, then across waves through LDS
+    // ---- 5. reduce: wave shuffles, then across waves through LDS
     float vals[FS_NACC];
     vals[0] = acc.info;
 #pragma unroll
@@ -176,17 +271,22 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     }
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < FS_NACC; ++i) red[wave * FS_NACC + i] = vals[i];
+        for (int i = 0; i < FS_NACC; ++i) sh_red[wave * FS_NACC + i] = vals[i];
     }
     __syncthreads();
     // cross-wave sums in fp64, one thread per quantity; the 6x6 assembly and log det run in
     // fs_fim_finish_kernel so that this kernel carries no private arrays
-    if (tid < FS_NACC) {
+    const bool failed = sh_overflow != 0;
+    if (tid < FS_NACC && !failed) {
         double x = 0.0;
-        for (int w = 0; w < FS_FIM_WAVES; ++w) x += (double)red[w * FS_NACC + tid];
-        if (!(sh_overflow && !GLOBAL_TABLE)) a.sums[(size_t)c * FS_NACC + tid] = x;
+        for (int w = 0; w < WAVES; ++w) x += (double)sh_red[w * FS_NACC + tid];
+        a.sums[(size_t)c * FS_NACC + tid] = x;
     }
-    if (tid == 0 && !GLOBAL_TABLE) a.overflow[c] = sh_overflow ? 1u : 0u;   // the overflow pass recomputes flagged candidates
+    if (tid == 0) {
+        a.overflow[c] = failed ? fail_code : 0u;                  // the next tier re-scores flagged candidates
+        atomicAdd(&a.counters[0], (unsigned long long)sh_tested * 64ull);          // landmarks tested (M_tested)
+        if (failed) atomicAdd(&a.counters[fail_code], 1ull);
+    }
     __syncthreads();
 }
 
@@ -196,37 +296,58 @@ __device__ __forceinline__ void zero_sums(const FsFimArgs &a, int c)
     if (threadIdx.x == 0) a.overflow[c] = 0u;
 }
 
-__global__ __launch_bounds__(FS_FIM_THREADS)
+// tier 1: one workgroup per candidate, 2^hash_bits LDS slots
+template <int THREADS>
+__global__ __launch_bounds__(THREADS)
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ uint32_t fs_fim_lds[];
-    uint32_t *table = fs_fim_lds;
-    float *red = reinterpret_cast<float *>(fs_fim_lds + (1u << a.hash_bits));
     const int c = blockIdx.x;
     if (c >= a.n) return;
     if (a.status && a.status[c] != FS_STATUS_OK) {           // blacklisted / off-map candidates carry zero FI
         zero_sums(a, c);
         return;
     }
-    fim_candidate<false>(a, c, table, a.hash_bits, red);
+    fim_candidate<THREADS, false>(a, c, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds), a.hash_bits, a.fail_code1);
 }
 
-// Second pass for candidates whose voxel set did not fit the LDS table: same code, table in HBM.
-__global__ __launch_bounds__(FS_FIM_THREADS)
-void fs_fim_overflow_kernel(const FsFimArgs a)
+// tier 2: candidates flagged 1 by tier 1; persistent workgroups with a larger LDS table
+template <int THREADS>
+__global__ __launch_bounds__(THREADS)
+void fs_fim_tier2_kernel(const FsFimArgs a)
 {
-    __shared__ float red[FS_FIM_WAVES * FS_NACC];
-    uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
+    extern __shared__ uint32_t fs_fim_lds[];
+    if (a.counters[1] == 0ull) return;                       // nothing was flagged
     for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
-        if (a.overflow[c] == 0u) continue;                   // uniform per workgroup
-        fim_candidate<true>(a, c, table, a.ghash_bits, red);
+        if (a.overflow[c] != 1u) continue;                   // uniform per workgroup
+        fim_candidate<THREADS, false>(a, c, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds), a.hash_bits2, 2u);
     }
 }
 
-// One thread per candidate: assemble the 6x6 FIM from the 17 block sums, trace, log det.
+// tier 3: candidates flagged 2; table in HBM with 2x the landmark count of slots and unbounded probing
+template <int THREADS>
+__global__ __launch_bounds__(THREADS)
+void fs_fim_tier3_kernel(const FsFimArgs a)
+{
+    extern __shared__ uint32_t fs_fim_lds[];
+    if (a.counters[2] == 0ull) return;
+    uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
+    for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
+        if (a.overflow[c] != 2u) continue;
+        fim_candidate<THREADS, true>(a, c, fs_fim_lds, table, a.ghash_bits, 3u);
+    }
+}
+
+// One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
 __global__ void fs_fim_finish_kernel(const FsFimArgs a)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) {                                            // per-call tier counters -> running totals
+        a.counters[4] += a.counters[1];
+        a.counters[5] += a.counters[2];
+        a.counters[6] += a.counters[3];
+        a.counters[1] = 0ull; a.counters[2] = 0ull; a.counters[3] = 0ull;
+    }
     if (c >= a.n) return;
     const double *S = a.sums + (size_t)c * FS_NACC;
     const double *A = S + 1, *B = S + 7, *Sv = S + 13;
@@ -286,33 +407,47 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
     a.n_voxels[c] = (int)(S[17] + 0.5);
 }
 
+template <int THREADS>
+size_t lds_bytes(int hash_bits, bool global_table)
+{
+    return sizeof(uint32_t) * (Lds<THREADS>::fixed_words + (global_table ? 0 : ((size_t)1 << hash_bits)));
+}
+
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 }  // namespace
 
-size_t fs_fim_lds_bytes(int hash_bits)
-{
-    return sizeof(uint32_t) * ((size_t)1 << hash_bits) + sizeof(float) * FS_FIM_WAVES * FS_NACC;
-}
+#define FS_T1_THREADS 512
+#define FS_T2_THREADS 1024
 
 hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s)
 {
     if (a.n <= 0) return hipSuccess;
-    const size_t lds = fs_fim_lds_bytes(a.hash_bits);
-    static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fs_fim_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
-    hipLaunchKernelGGL(fs_fim_kernel, dim3(a.n), dim3(FS_FIM_THREADS), lds, s, a);
+    const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false);
+    hipError_t e = allow_lds(fs_fim_kernel<FS_T1_THREADS>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fs_fim_kernel<FS_T1_THREADS>, dim3(a.n), dim3(FS_T1_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s)
 {
     if (a.n <= 0) return hipSuccess;
+    if (a.hash_bits2 > a.hash_bits) {
+        const size_t lds2 = lds_bytes<FS_T2_THREADS>(a.hash_bits2, false);
+        hipError_t e = allow_lds(fs_fim_tier2_kernel<FS_T2_THREADS>, lds2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fs_fim_tier2_kernel<FS_T2_THREADS>, dim3(a.n < 256 ? a.n : 256), dim3(FS_T2_THREADS), lds2, s, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     const int blocks = a.n < pool ? a.n : pool;
-    hipLaunchKernelGGL(fs_fim_overflow_kernel, dim3(blocks), dim3(FS_FIM_THREADS), 0, s, a);
+    const size_t lds3 = lds_bytes<FS_T2_THREADS>(0, true);
+    hipLaunchKernelGGL(fs_fim_tier3_kernel<FS_T2_THREADS>, dim3(blocks), dim3(FS_T2_THREADS), lds3, s, a);
     return hipGetLastError();
 }
 

@@ -44,19 +44,24 @@ struct FsRayArgs {
 
 // ---- FIM kernel arguments ---------------------------------------------------------------------
 struct FsFimArgs {
-    // landmarks, SoA, padded to a multiple of FS_LM_PAD with far-away sentinels
+    // landmarks: Morton-ordered SoA, n_chunks chunks of 64 (the tail padded with far-away sentinels),
+    // one bounding sphere (cx, cy, cz, r + safety margin) per chunk
     const float *lx, *ly, *lz;
-    int32_t m_padded;
+    const float *spheres;      // [n_chunks][4]
+    int32_t n_chunks;
+    int32_t cull;              // 0: every chunk is tested (brute force)
     // dense lookup table indexed by the integer voxel lattice
     const float *table;        // [tx][ty][tz], NaN = absent
     int32_t jx0, jy0, jz0;     // lattice index of table[0][0][0]
     int32_t tx, ty, tz;
     double inv_step;           // 1 / (double)0.3f  (FisherInfoManager.hpp:119)
+    float inv_step_f;          // (float)inv_step, fast path of the voxel index
     const float *factor;       // crowding factor by rank, [FS_FACTOR_N]; rank >= FS_FACTOR_N -> 0
     // visibility
     float maxd2;               // (float)(max_dist^2)
     float cos2;                // c*c, c = (float)cos(max_angle)
-    int32_t cone_mode;         // 0 disabled, 1 c >= 0, 2 c < 0
+    int32_t cone_mode;         // 0 disabled, 1 c >= 0 (cone also culled per chunk), 2 c < 0, 3 c >= 0 but too wide to cull
+    float max_dist_f, cos_a, sin_a;   // chunk culling (cone culled only in mode 1)
     // poses: either explicit Rt[n][12] (R row-major 9 + t 3) or from the arrival outputs
     int32_t n;
     const float *Rt;           // explicit poses or nullptr
@@ -68,14 +73,17 @@ struct FsFimArgs {
     float *info_ref, *trace, *logdet, *fim21;   // fim21 may be nullptr
     int32_t *n_visible, *n_voxels;
     double *sums;              // [n][18] reduced per-candidate sums (info, 15 FIM block sums, n_visible, n_voxels)
-    uint32_t *overflow;        // [n] set to 1 when the LDS table filled up (second pass needed)
-    // hash table
-    int32_t hash_bits;
-    uint32_t *gtable;          // global-memory tables for the overflow pass: [pool][1 << ghash_bits]
+    uint32_t *overflow;        // [n] tier that must re-score the candidate (0 = done)
+    unsigned long long *counters;   // [8]: 0 landmarks tested, 1..3 per-call tier failures, 4..6 their running totals
+    // hash tables
+    int32_t hash_bits;         // tier 1 (LDS, 512-thread workgroups)
+    int32_t hash_bits2;        // tier 2 (LDS, 1024-thread workgroups); <= hash_bits disables the tier
+    uint32_t fail_code1;       // what tier 1 flags on failure: 1 (tier 2 exists) or 2 (straight to tier 3)
+    uint32_t *gtable;          // tier 3: HBM tables [pool][1 << ghash_bits]
     int32_t ghash_bits;
 };
 
-#define FS_LM_PAD      4096     // landmark arrays are padded to a multiple of this (1024 threads x 4)
+#define FS_CHUNK       64       // landmarks per chunk (one wave)
 #define FS_FACTOR_N    512      // exp(1 - k^0.8) underflows to 0.0f for k > ~340
 #define FS_SLOT_CNT_BITS 11     // slot = (key+1) << 11 | count
 #define FS_SLOT_CNT_MASK ((1u << FS_SLOT_CNT_BITS) - 1u)

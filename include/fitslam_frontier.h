@@ -109,6 +109,13 @@ int  fs_synchronize(fs_ctx *ctx);
 int  fs_enable_kernel_timing(fs_ctx *ctx, int enable);
 int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
 
+/* Tuning / diagnostic knobs (no reference counterpart).  Keys: "fim.cull" (default 1): per-chunk
+ * bounding-sphere culling of the landmark cloud; 0 tests every landmark (brute force; identical results). */
+int  fs_set_option(fs_ctx *ctx, const char *key, double value);
+/* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
+ * 4/5/6 = candidates re-scored by the second / third hash-table tier / unresolved (always 0). */
+int  fs_get_counter(fs_ctx *ctx, int which, int64_t *value, int reset);
+
 /* ---------------------------------------------------------------- arrival information (ray-cast) */
 
 /* Replaces FrontierCostCalculator::FrontierCostCalculator (DEP/src/CostCalculator.cpp:5-21). */

@@ -258,3 +258,33 @@ def test_rank_matches_oracle(fs, oracle, scorer):
     for k in ("weighted_cost", "arrival_utility", "distance_utility"):
         np.testing.assert_array_equal(got[k], want[k])
     np.testing.assert_array_equal(got["order"], np.argsort(want["weighted_cost"], kind="stable"))
+
+
+def test_fim_culling_is_exact(fs, oracle, scorer, ref_table):
+    """Chunk culling (Morton-ordered landmark chunks + bounding spheres) must leave the visible set, the
+    voxel counts and the FI untouched; it only removes work."""
+    w = fs.synth.make_workload("C2", n_cand=400)
+    rng = np.random.default_rng(17)
+    poses = oracle.poses_from_yaw(w.goals, rng.uniform(-np.pi, np.pi, size=400))
+    _setup_scorer(scorer, w)
+    out = {}
+    for cull in (1, 0):
+        scorer.set_option("fim.cull", cull)
+        scorer.get_counter(0, reset=True)
+        out[cull] = scorer.score_fim(poses)
+        out[cull]["tested"] = scorer.get_counter(0, reset=True)
+    scorer.set_option("fim.cull", 1)
+    m_pad = -(-w.landmarks.shape[0] // 64) * 64
+    # every candidate tests the whole cloud once (a candidate re-scored by a larger hash tier tests it again)
+    assert 400 * m_pad <= out[0]["tested"] <= 1.05 * 400 * m_pad and out[0]["tested"] % m_pad == 0
+    assert out[1]["tested"] < 0.5 * out[0]["tested"]
+    for k in ("n_visible", "n_voxels"):
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+    np.testing.assert_allclose(out[0]["info_ref"], out[1]["info_ref"], rtol=2e-6)
+    want = oracle.pose_information(ref_table, w.landmarks, poses, 14.0, 1.0, n_threads=8)
+    _check_fim(out[1], want, w.landmarks.shape[0])
+    # a non-unit quaternion (Eigen would not normalise it) silently falls back to the brute-force scan
+    bad = poses[:4].copy(); bad[:, 3:] *= 1.3
+    got = scorer.score_fim(bad)
+    want = oracle.pose_information(ref_table, w.landmarks, bad, 14.0, 1.0)
+    np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
