@@ -76,6 +76,9 @@ struct fs_ctx {
     int32_t m = 0, n_chunks = 0;
     DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
     bool opt_cull = true;
+    int opt_ablate = 0;
+    bool opt_debug = false;
+    DevBuf<unsigned long long> d_dbg;
     DevBuf<unsigned long long> d_counters;
 
     // lookup table
@@ -85,6 +88,8 @@ struct fs_ctx {
     int32_t jx0 = 0, jy0 = 0, jz0 = 0, tx = 0, ty = 0, tz = 0;
     DevBuf<float> d_table, d_factor;
     bool have_factor = false;
+    bool table_full = false;
+    float fac[5] = {0, 0, 0, 0, 0};
 
     // fim parameters
     fs_fim_params fp{14.0, 1.0};
@@ -99,7 +104,9 @@ struct fs_ctx {
     DevBuf<int32_t> d_fsize, d_arrival, d_argmax, d_status, d_nvis, d_nvox, d_raycounts, d_order, d_err;
     DevBuf<uint8_t> d_black, d_achin, d_ach;
     DevBuf<float> d_info, d_trace, d_logdet, d_fim21, d_Rt;
-    DevBuf<uint32_t> d_overflow;
+    DevBuf<uint32_t> d_overflow, d_tested;
+    DevBuf<int32_t> d_flagged;
+    size_t tested_zeroed = 0;
     DevBuf<fs_record> d_records;
     void *rank_scratch = nullptr;
     size_t rank_scratch_bytes = 0;
@@ -292,6 +299,8 @@ int build_dense(fs_ctx *c)
         const size_t idx = ((size_t)(lat[3 * i] - lo[0]) * dy + (size_t)(lat[3 * i + 1] - lo[1])) * dz + (size_t)(lat[3 * i + 2] - lo[2]);
         c->dense[idx] = c->records[4 * i + 3];
     }
+    c->table_full = true;
+    for (float v : c->dense) if (std::isnan(v)) { c->table_full = false; break; }
     FS_HIP(c, c->d_table.ensure(c->dense.size()));
     FS_HIP(c, hipMemcpyAsync(c->d_table.p, c->dense.data(), c->dense.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (!c->have_factor) {
@@ -299,6 +308,7 @@ int build_dense(fs_ctx *c)
         std::vector<float> fac(FS_FACTOR_N, 0.0f);
         const float s = 0.8f;
         for (int k = 1; k < FS_FACTOR_N; ++k) fac[k] = (float)std::exp(1 - std::pow((double)k, (double)s));
+        for (int k = 1; k <= 4; ++k) c->fac[k] = fac[k];
         FS_HIP(c, c->d_factor.ensure(fac.size()));
         FS_HIP(c, hipMemcpyAsync(c->d_factor.p, fac.data(), fac.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         FS_HIP(c, hipStreamSynchronize(c->stream));
@@ -362,12 +372,15 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     a.spheres = c->d_spheres.p;
     a.n_chunks = c->n_chunks;
     a.cull = c->opt_cull ? 1 : 0;
+    a.ablate = c->opt_ablate;
     a.table = c->d_table.p;
     a.jx0 = c->jx0; a.jy0 = c->jy0; a.jz0 = c->jz0;
     a.tx = c->tx; a.ty = c->ty; a.tz = c->tz;
     a.inv_step = 1 / (double)kStepMax;
     a.inv_step_f = (float)a.inv_step;
     a.factor = c->d_factor.p;
+    a.fac1 = c->fac[1]; a.fac2 = c->fac[2]; a.fac3 = c->fac[3]; a.fac4 = c->fac[4];
+    a.table_full = c->table_full ? 1 : 0;
     a.maxd2 = (float)(c->fp.max_dist * c->fp.max_dist);
     a.max_dist_f = (float)c->fp.max_dist * 1.0001f + 1.0e-3f;      // culling reach, rounded outwards
     if (c->fp.max_angle >= M_PI) {
@@ -401,6 +414,11 @@ int ensure_candidate_scratch(fs_ctx *c, size_t n, bool want_fim21)
     FS_HIP(c, c->d_info.ensure(n)); FS_HIP(c, c->d_trace.ensure(n)); FS_HIP(c, c->d_logdet.ensure(n));
     FS_HIP(c, c->d_nvis.ensure(n)); FS_HIP(c, c->d_nvox.ensure(n)); FS_HIP(c, c->d_overflow.ensure(n));
     FS_HIP(c, c->d_sums.ensure(n * 18));
+    FS_HIP(c, c->d_flagged.ensure(n * 2));
+    if (c->d_tested.cap < n) {
+        FS_HIP(c, c->d_tested.ensure(n));
+        FS_HIP(c, hipMemsetAsync(c->d_tested.p, 0, c->d_tested.cap * sizeof(uint32_t), c->stream));
+    }
     if (want_fim21) FS_HIP(c, c->d_fim21.ensure(n * 21));
     return FS_OK;
 }
@@ -454,7 +472,7 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_nvis.release(); c->d_nvox.release(); c->d_raycounts.release(); c->d_order.release(); c->d_err.release();
     c->d_black.release(); c->d_achin.release(); c->d_ach.release();
     c->d_info.release(); c->d_trace.release(); c->d_logdet.release(); c->d_fim21.release(); c->d_Rt.release();
-    c->d_overflow.release(); c->d_records.release();
+    c->d_overflow.release(); c->d_tested.release(); c->d_flagged.release(); c->d_records.release();
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -795,7 +813,18 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
 {
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "fim.ablate") == 0) { c->opt_ablate = (int)value; return FS_OK; }   // development only
+    if (std::strcmp(key, "fim.debug") == 0) { c->opt_debug = value != 0.0; return FS_OK; }    // development only
     return fail(c, FS_E_INVALID, "unknown option %s", key);
+}
+
+int fs_debug_fetch(fs_ctx *c, int32_t n, uint64_t *out)
+{
+    if (!c || !out || !c->d_dbg.p) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    FS_HIP(c, hipMemcpyAsync(out, c->d_dbg.p, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    return FS_OK;
 }
 
 int fs_get_counter(fs_ctx *c, int which, int64_t *value, int reset)
@@ -901,6 +930,14 @@ static int run_fim(fs_ctx *c, FsFimArgs &a)
     a.info_ref = c->d_info.p; a.trace = c->d_trace.p; a.logdet = c->d_logdet.p;
     a.n_visible = c->d_nvis.p; a.n_voxels = c->d_nvox.p; a.overflow = c->d_overflow.p;
     a.sums = c->d_sums.p;
+    a.tested = c->d_tested.p;
+    a.flagged = c->d_flagged.p;
+    a.dbg = nullptr;
+    if (c->opt_debug) {
+        FS_HIP(c, c->d_dbg.ensure((size_t)a.n * 8));
+        FS_HIP(c, hipMemsetAsync(c->d_dbg.p, 0, (size_t)a.n * 8 * sizeof(unsigned long long), c->stream));
+        a.dbg = c->d_dbg.p;
+    }
     {
         ScopedTimer t(c, 1);
         FS_HIP(c, fs_launch_fim(a, c->stream));

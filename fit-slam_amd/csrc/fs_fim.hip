@@ -7,8 +7,8 @@
 // Data: the landmark cloud is staged once (fs_upload_landmarks) in Morton order as SoA fp32 and cut
 // into chunks of 64 consecutive landmarks, each with a bounding sphere.  One workgroup scores one
 // candidate:
-//   1. cull   — every lane tests chunk spheres against the visibility volume (range sphere + cone,
-//               conservative); accepted chunk ids go to an LDS list.  Only a few per cent of a 512^3
+//   1. cull   — chunk k belongs to wave (k mod waves); every lane tests one chunk sphere against the
+//               visibility volume (range sphere + cone, conservative) and the wave walks the ballot mask.  Only a few per cent of a 512^3
 //               map's cloud survives, so the per-landmark work drops by an order of magnitude while the
 //               visible set stays exactly the brute-force one (the exact predicate is re-evaluated
 //               per landmark).
@@ -32,7 +32,6 @@
 
 #define FS_NACC 18       // info, 15 FIM block sums, n_visible, n_voxels
 #define FS_QCAP 128      // per-wave compaction queue (<= 63 left over + 64 new)
-#define FS_LIST_SEG 512  // accepted-chunk list segment (chunks culled per pass)
 #define FS_MAX_PROBE 96  // LDS tiers give up (-> next tier) after this many probes
 
 namespace {
@@ -83,14 +82,16 @@ __device__ __forceinline__ int voxel_index(float p, double inv_step, float inv_s
     const float r = p * inv_step_f;
     const float rn = rintf(r);
     const float frac = fabsf(r - rn);
-    if (frac < 0.49f && fabsf(r) < 1024.0f) return (int)rn;
+    if (frac < 0.4995f && fabsf(r) < 1024.0f) return (int)rn;     // 5e-4 >> the fp32 product's error bound 1.4e-4
     return (int)round((double)p * inv_step);
 }
 
-__device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *table, int bits, uint32_t max_probe,
+// returns true when this landmark opened a new voxel entry
+__device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
                                               float px, float py, float pz, Acc &acc, bool &overflow)
 {
     acc.nvis += 1;
+    if (a.ablate & 1) return false;
     // dense-table lookup first: its latency overlaps the FIM arithmetic below
     const int jx = voxel_index(px, a.inv_step, a.inv_step_f) - a.jx0;
     const int jy = voxel_index(py, a.inv_step, a.inv_step_f) - a.jy0;
@@ -98,13 +99,13 @@ __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *tabl
     const bool in_table = (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
     const uint32_t key = ((uint32_t)jx * (uint32_t)a.ty + (uint32_t)jy) * (uint32_t)a.tz + (uint32_t)jz;
     float info_v = __builtin_nanf("");
-    if (in_table) info_v = a.table[key];                     // key miss -> NaN -> skipped (:90-94)
+    if (in_table) info_v = (a.ablate & 4) ? 2.0f : a.table[key];
 
     // unit-weight FIM block sums, F(p) = [[P/n^2, -S/n^2],[S/n^2, P]].  P's diagonal is
     // formed as a sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector
     // has no Jacobian.
     const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
-    if (n2 > 0.0f) {
+    if (n2 > 0.0f && !(a.ablate & 8)) {
         const float q = 1.0f / n2;
         const float qx = px * q, qy = py * q, qz = pz * q;
         const float xx = px * qx, yy = py * qy, zz = pz * qz;
@@ -113,38 +114,64 @@ __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *tabl
         for (int i = 0; i < 6; ++i) { acc.A[i] += v[i]; acc.B[i] += v[i] * q; }
         acc.s[0] += qx; acc.s[1] += qy; acc.s[2] += qz;
     }
-    if (info_v != info_v) return;                            // absent lattice point
-    bool is_new;
-    const uint32_t rank = table_bump(table, bits, key, max_probe, is_new);
-    if (rank == 0u) { overflow = true; return; }
+    // A table without holes inside its box (every generated table) lets the hash update start without
+    // waiting for the gathered value; otherwise absent lattice points must be skipped first.
+    if (!in_table) return false;                             // key miss -> NaN -> skipped (:90-94)
+    if (!a.table_full && info_v != info_v) return false;     // absent lattice point
+    bool is_new = false;
+    const uint32_t rank = (a.ablate & 2) ? 1u : table_bump(table, bits, key, max_probe, is_new);
+    if (rank == 0u) { overflow = true; return false; }
     if (is_new) acc.nvox += 1;                               // occupied_voxel_count_++ (:304)
-    const float fac = rank < FS_FACTOR_N ? a.factor[rank] : 0.0f;
+    // crowding factor exp(1 - k^0.8): ranks 1..4 from scalar registers, the rest from the table
+    float fac = a.fac1;
+    if (rank > 1u) fac = (rank == 2u) ? a.fac2 : (rank == 3u) ? a.fac3 : (rank == 4u) ? a.fac4
+                       : (rank < FS_FACTOR_N ? lfac[rank] : 0.0f);
     // :318 — (float)(double information * float factor): the double product of two floats is exact,
     // so one rounding to float == the fp32 product
     acc.info += info_v * fac;
+    return is_new;
 }
 
-// dynamic-LDS carve-up of one workgroup: [per-wave queues][accepted-chunk list][hash table]
+// wave64 sum with DPP row operations (no LDS traffic): the total lands in lane 63
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+#define FS_DPP_ADD(ctrl, rmask)                                                                              \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true))
+    FS_DPP_ADD(0x111, 0xf);   // row_shr:1
+    FS_DPP_ADD(0x112, 0xf);   // row_shr:2
+    FS_DPP_ADD(0x114, 0xf);   // row_shr:4
+    FS_DPP_ADD(0x118, 0xf);   // row_shr:8   -> lane 15 of each row holds the row sum
+    FS_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    FS_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef FS_DPP_ADD
+    return v;
+}
+
+// dynamic-LDS carve-up of one workgroup: [per-wave compaction queues][hash table]
 template <int THREADS>
 struct Lds {
     static constexpr int WAVES = THREADS / 64;
-    static constexpr size_t fixed_words = (size_t)WAVES * 3 * FS_QCAP + FS_LIST_SEG / 2;
+    static constexpr size_t fixed_words = (size_t)WAVES * 3 * FS_QCAP + FS_FACTOR_N;   // + 2 * WAVES * n_groups mask words, then the table
+    static __device__ __forceinline__ unsigned long long *masks(uint32_t *base, int) { return reinterpret_cast<unsigned long long *>(base + fixed_words); }
+    static __device__ __forceinline__ float *factor(uint32_t *base) { return reinterpret_cast<float *>(base) + WAVES * 3 * FS_QCAP; }
     static __device__ __forceinline__ float *queue(uint32_t *base, int wave) { return reinterpret_cast<float *>(base) + wave * (3 * FS_QCAP); }
-    static __device__ __forceinline__ uint16_t *list(uint32_t *base) { return reinterpret_cast<uint16_t *>(base + WAVES * 3 * FS_QCAP); }
-    static __device__ __forceinline__ uint32_t *table(uint32_t *base) { return base + fixed_words; }
+    static __device__ __forceinline__ uint32_t *table(uint32_t *base, int n_groups) { return base + fixed_words + 2 * WAVES * n_groups + ((2 * WAVES * n_groups) & 2); }
 };
 
 template <int THREADS, bool GLOBAL_TABLE>
 __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_t *lds, uint32_t *table, int bits,
-                                              uint32_t fail_code)
+                                              uint32_t fail_code, bool last_use)
 {
     constexpr int WAVES = THREADS / 64;
     const uint32_t max_probe = GLOBAL_TABLE ? (1u << bits) : FS_MAX_PROBE;
+    const int tier_bits = bits;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    __shared__ int sh_overflow, sh_count, sh_tested;
+    __shared__ int sh_overflow, sh_nvox, sh_wave_tested[WAVES];
     __shared__ float sh_red[WAVES * FS_NACC];
 
+    const unsigned long long dbg_t0 = a.dbg ? wall_clock64() : 0ull;
+    unsigned long long st2 = 0, st3 = 0, sc_clk = 0, sc_n = 0;
     // ---- pose
     float R[9], t[3];
     if (a.Rt) {
@@ -160,15 +187,74 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
         for (int i = 0; i < 3; ++i) t[i] = (float)a.goal[3 * (size_t)c + i];   // getTransformFromPose: float translation
     }
 
-    // ---- clear the hash table
-    const uint32_t slots = 1u << bits;
-    if (GLOBAL_TABLE) {
-        for (uint32_t i = tid; i < slots; i += THREADS) table[i] = 0u;
-    } else {
-        uint4 *t4 = reinterpret_cast<uint4 *>(table);
-        for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+    // px = ax*dx + ay*dy + az*dz: the camera's +x axis in the world frame
+    const float ax = R[0], ay = R[3], az = R[6];
+    const float4 *__restrict__ spheres = reinterpret_cast<const float4 *>(a.spheres);
+    const float *__restrict__ LX = a.lx, *__restrict__ LY = a.ly, *__restrict__ LZ = a.lz;
+    constexpr int STRIDE = WAVES * 64;
+    unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
+
+    // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass.
+    // All passes are issued before the table is cleared so that their latency overlaps the clear.
+    int tested = 0;                                            // wave-uniform: chunks this wave will scan
+    for (int g = 0; g < a.n_groups; ++g) {
+        const int j = g * STRIDE + lane * WAVES + wave;
+        bool keep = j < a.n_chunks;
+        if (keep && a.cull) {
+            const float4 s = spheres[j];                       // s.w carries a safety margin: the test is conservative
+            const float dx = s.x - t[0], dy = s.y - t[1], dz = s.z - t[2];
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const float reach = a.max_dist_f + s.w;
+            keep = d2 <= reach * reach;
+            if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
+                // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|)
+                const float dist = sqrtf(d2);
+                const float sb = s.w / dist;                           // < 1 here
+                const float cb = sqrtf(fmaxf(0.0f, 1.0f - sb * sb));
+                const float cab = a.cos_a * cb - a.sin_a * sb;          // cos(alpha + beta)
+                const float dot = dx * ax + dy * ay + dz * az;
+                keep = dot >= dist * cab - 1.0e-4f * dist - 1.0e-4f;
+            }
+        }
+        unsigned long long mask = __ballot(keep);
+        if (a.ablate & 16) mask = 0ull;
+        tested += __popcll(mask);
+        if (lane == 0) masks[g] = mask;
     }
-    if (tid == 0) { sh_overflow = 0; sh_tested = 0; }
+
+    // chunks accepted by the whole workgroup: every wave publishes its count, one barrier, everyone sums
+    if (lane == 0) sh_wave_tested[wave] = tested;
+    if (tid == 0) { sh_overflow = 0; sh_nvox = 0; }
+    float *lfac = Lds<THREADS>::factor(lds);
+    for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
+    __syncthreads();
+    int wg_tested = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) wg_tested += sh_wave_tested[w];
+
+    // ---- size and clear the hash table.  Distinct voxels are at most ~0.5 of the landmarks scanned (measured
+    // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
+    // candidates clear only a small table.  A candidate that could overfill this tier's largest table
+    // (more than 3/4 full: linear probing crawls) goes straight to the next tier; the running voxel count in the
+    // main loop is the exact safety net.
+    const bool skip_tier = !GLOBAL_TABLE && ((long long)wg_tested * 64 * 15 > (long long)(3 << (tier_bits - 2)) * 32);
+    if (!GLOBAL_TABLE) {
+        int need = 10;
+        while (need < tier_bits && (1 << need) < wg_tested * 64) ++need;
+        bits = need;
+    }
+    const uint32_t slots = 1u << bits;
+    const int nvox_limit = GLOBAL_TABLE ? 0x7fffffff : (int)((slots >> 2) * 3u);
+    if (!skip_tier) {
+        if (GLOBAL_TABLE) {
+            for (uint32_t i = tid; i < slots; i += THREADS) table[i] = 0u;
+        } else {
+            uint4 *t4 = reinterpret_cast<uint4 *>(table);
+            for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __syncthreads();
+    bool overflow = false;
 
     Acc acc;
     acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
@@ -176,54 +262,39 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     for (int i = 0; i < 6; ++i) { acc.A[i] = 0.f; acc.B[i] = 0.f; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) acc.s[i] = 0.f;
-    bool overflow = false;
 
     float *qx = Lds<THREADS>::queue(lds, wave), *qy = qx + FS_QCAP, *qz = qy + FS_QCAP;
-    uint16_t *list = Lds<THREADS>::list(lds);
     int qcount = 0;                                            // wave-uniform
-    int tested = 0;
+    volatile int *v_overflow = &sh_overflow;
+    volatile int *v_nvox = &sh_nvox;
+    if (skip_tier) { overflow = true; if (tid == 0) *v_overflow = 1; }
 
-    // cone axis in the world frame = first column of R^T's row 0, i.e. px = ax*dx + ay*dy + az*dz
-    const float ax = R[0], ay = R[3], az = R[6];
-    const float4 *__restrict__ spheres = reinterpret_cast<const float4 *>(a.spheres);
-
-    for (int seg = 0; seg < a.n_chunks; seg += FS_LIST_SEG) {
-        if (tid == 0) sh_count = 0;
-        __syncthreads();
-        // ---- 1. cull: one chunk sphere per lane (conservative: s.w carries a safety margin)
-        const int seg_end = min(a.n_chunks, seg + FS_LIST_SEG);
-        for (int j = seg + tid; j < seg_end; j += THREADS) {
-            bool keep = true;
-            if (a.cull) {
-                const float4 s = spheres[j];
-                const float dx = s.x - t[0], dy = s.y - t[1], dz = s.z - t[2];
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                const float reach = a.max_dist_f + s.w;
-                keep = d2 <= reach * reach;
-                if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
-                    // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|)
-                    const float dist = sqrtf(d2);
-                    const float sb = s.w / dist;                           // < 1 here
-                    const float cb = sqrtf(fmaxf(0.0f, 1.0f - sb * sb));
-                    const float cab = a.cos_a * cb - a.sin_a * sb;          // cos(alpha + beta)
-                    const float dot = dx * ax + dy * ay + dz * az;
-                    keep = dot >= dist * cab - 1.0e-4f * dist - 1.0e-4f;
-                }
-            }
-            if (keep) {
-                const int pos = atomicAdd(&sh_count, 1);
-                list[pos] = (uint16_t)(j - seg);
-            }
+    // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
+    // next chunk's landmarks prefetched into registers while the current one is processed.
+    for (int g = 0; g < a.n_groups && !skip_tier; ++g) {
+        const int g0 = g * STRIDE;
+        unsigned long long mask = masks[g];
+        mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
+               ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
+        if (!GLOBAL_TABLE) {
+            if (*v_overflow) break;                                // another wave ran out of table: the next tier redoes it
+            // distinct voxels so far, extrapolated over the chunks still to come (Morton order interleaved over
+            // the waves makes the prefix representative): a table that clearly will not fit is handed on early
+            if (g > 0 && (long long)(*v_nvox) * a.n_chunks > (long long)nvox_limit * g0 * 5 / 4) { overflow = true; *v_overflow = 1; break; }
         }
-        __syncthreads();
-        const int count = sh_count;
-        if (tid == 0) tested += count;
-        // ---- 2./3./4. one wave per accepted chunk
-        for (int i = wave; i < count; i += WAVES) {
-            const int chunk = seg + (int)list[i];
-            const int l = chunk * 64 + lane;
-            const float wx = a.lx[l], wy = a.ly[l], wz = a.lz[l];
-            // p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
+        int cur = -1;
+        if (mask) { cur = g0 + __builtin_ctzll(mask) * WAVES + wave; mask &= mask - 1ull; }
+        float wx = 0.f, wy = 0.f, wz = 0.f;
+        if (cur >= 0) { const int l = cur * 64 + lane; wx = LX[l]; wy = LY[l]; wz = LZ[l]; }
+        while (cur >= 0) {
+            int nxt = -1;
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            if (mask) {
+                nxt = g0 + __builtin_ctzll(mask) * WAVES + wave; mask &= mask - 1ull;
+                const int l = nxt * 64 + lane;
+                nx = LX[l]; ny = LY[l]; nz = LZ[l];
+            }
+            // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
             const float dx = wx - t[0], dy = wy - t[1], dz = wz - t[2];
             const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
             const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
@@ -232,6 +303,7 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
             bool vis = (n2 <= a.maxd2);
             if (a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
             else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px * px <= a.cos2 * n2));
+            // ---- 3. compact
             const unsigned long long m = __ballot(vis);
             if (m != 0ull) {
                 if (vis) {
@@ -242,16 +314,24 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
                 if (qcount >= 64) {
                     qcount -= 64;                                  // take the newest 64: the remainder stays in place
                     const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
-                    score_visible(a, table, bits, max_probe, ex, ey, ez, acc, overflow);
+                    // ---- 4. score
+                    const bool opened = score_visible(a, table, lfac, bits, max_probe, ex, ey, ez, acc, overflow);
+                    const unsigned long long om = __ballot(opened);
+                    if (!GLOBAL_TABLE && om != 0ull) {
+                        int total = 0;
+                        if (lane == 0) total = atomicAdd(&sh_nvox, (int)__popcll(om)) + (int)__popcll(om);
+                        if (__builtin_amdgcn_readfirstlane(total) > nvox_limit) overflow = true;
+                    }
+                    if (__any(overflow)) *v_overflow = 1;
                 }
             }
+            cur = nxt; wx = nx; wy = ny; wz = nz;
         }
-        __syncthreads();                                           // list / sh_count are reused by the next segment
     }
+    if (skip_tier) qcount = 0;
     // flush the queue remainder
-    if (lane < qcount) score_visible(a, table, bits, max_probe, qx[lane], qy[lane], qz[lane], acc, overflow);
-    if (overflow) sh_overflow = 1;
-    if (tid == 0) sh_tested = tested;
+    if (lane < qcount) score_visible(a, table, lfac, bits, max_probe, qx[lane], qy[lane], qz[lane], acc, overflow);
+    if (overflow) *v_overflow = 1;
 
     // ---- 5. reduce: wave shuffles, then across waves through LDS
     float vals[FS_NACC];
@@ -263,13 +343,8 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     vals[16] = (float)acc.nvis;     // exact: < 2^24 per lane
     vals[17] = (float)acc.nvox;
 #pragma unroll
-    for (int i = 0; i < FS_NACC; ++i) {
-        float x = vals[i];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-        vals[i] = x;
-    }
-    if (lane == 0) {
+    for (int i = 0; i < FS_NACC; ++i) vals[i] = wave_sum_dpp(vals[i]);
+    if (lane == 63) {
 #pragma unroll
         for (int i = 0; i < FS_NACC; ++i) sh_red[wave * FS_NACC + i] = vals[i];
     }
@@ -284,16 +359,27 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     }
     if (tid == 0) {
         a.overflow[c] = failed ? fail_code : 0u;                  // the next tier re-scores flagged candidates
-        atomicAdd(&a.counters[0], (unsigned long long)sh_tested * 64ull);          // landmarks tested (M_tested)
-        if (failed) atomicAdd(&a.counters[fail_code], 1ull);
+        if (!skip_tier) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u);       // landmarks tested (M_tested), summed by the finish kernel
+        if (failed && fail_code < 3u) {
+            const unsigned long long slot = atomicAdd(&a.counters[fail_code], 1ull);
+            a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
+        } else if (failed) {
+            atomicAdd(&a.counters[3], 1ull);
+        }
+        if (a.dbg) {
+            const int tier = GLOBAL_TABLE ? 2 : ((tier_bits == a.hash_bits2 && a.hash_bits2 > a.hash_bits) ? 1 : 0);
+            unsigned long long *d = a.dbg + 8 * (size_t)c;
+            d[tier] = wall_clock64() - dbg_t0;
+            if (tier == 0) { d[3] = (unsigned long long)wg_tested; d[4] = sc_n; d[5] = st3 - st2; d[6] = sc_clk; }
+        }
     }
-    __syncthreads();
+    if (!last_use) __syncthreads();                                // LDS is reused by the workgroup's next candidate
 }
 
 __device__ __forceinline__ void zero_sums(const FsFimArgs &a, int c)
 {
     if (threadIdx.x < FS_NACC) a.sums[(size_t)c * FS_NACC + threadIdx.x] = 0.0;
-    if (threadIdx.x == 0) a.overflow[c] = 0u;
+    if (threadIdx.x == 0) { a.overflow[c] = 0u; }
 }
 
 // tier 1: one workgroup per candidate, 2^hash_bits LDS slots
@@ -301,52 +387,62 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_kernel(const FsFimArgs a)
 {
-    extern __shared__ uint32_t fs_fim_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const int c = blockIdx.x;
     if (c >= a.n) return;
     if (a.status && a.status[c] != FS_STATUS_OK) {           // blacklisted / off-map candidates carry zero FI
         zero_sums(a, c);
         return;
     }
-    fim_candidate<THREADS, false>(a, c, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds), a.hash_bits, a.fail_code1);
+    fim_candidate<THREADS, false>(a, c, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits, a.fail_code1, true);
 }
 
-// tier 2: candidates flagged 1 by tier 1; persistent workgroups with a larger LDS table
+// tier 2: candidates tier 1 appended to its work list; persistent workgroups with a larger LDS table pull
+// items from a device-side counter (heavy candidates differ a lot in cost: static striding left a long tail)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_tier2_kernel(const FsFimArgs a)
 {
-    extern __shared__ uint32_t fs_fim_lds[];
-    if (a.counters[1] == 0ull) return;                       // nothing was flagged
-    for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
-        if (a.overflow[c] != 1u) continue;                   // uniform per workgroup
-        fim_candidate<THREADS, false>(a, c, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds), a.hash_bits2, 2u);
+    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
+    __shared__ int sh_item;
+    const int count = (int)a.counters[1];
+    for (;;) {
+        if (threadIdx.x == 0) sh_item = (int)atomicAdd(&a.counters[7], 1ull);
+        __syncthreads();
+        const int i = sh_item;
+        __syncthreads();
+        if (i >= count) break;
+        fim_candidate<THREADS, false>(a, a.flagged[i], fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2, 2u, false);
     }
 }
 
-// tier 3: candidates flagged 2; table in HBM with 2x the landmark count of slots and unbounded probing
+// tier 3: candidates on the second work list; table in HBM with 2x the landmark count of slots and unbounded probing
 template <int THREADS>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_tier3_kernel(const FsFimArgs a)
 {
-    extern __shared__ uint32_t fs_fim_lds[];
-    if (a.counters[2] == 0ull) return;
+    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
+    const int count = (int)a.counters[2];
     uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
-    for (int c = blockIdx.x; c < a.n; c += gridDim.x) {
-        if (a.overflow[c] != 2u) continue;
-        fim_candidate<THREADS, true>(a, c, fs_fim_lds, table, a.ghash_bits, 3u);
-    }
+    for (int i = blockIdx.x; i < count; i += gridDim.x)
+        fim_candidate<THREADS, true>(a, a.flagged[(size_t)a.n + i], fs_fim_lds, table, a.ghash_bits, 3u, false);
 }
 
 // One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
 __global__ void fs_fim_finish_kernel(const FsFimArgs a)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    {   // landmark-test count of this block's candidates -> one atomic per block
+        unsigned long long tsum = (c < a.n) ? (unsigned long long)a.tested[c] : 0ull;
+        if (c < a.n) a.tested[c] = 0u;
+        for (int d = 32; d >= 1; d >>= 1) tsum += __shfl_xor(tsum, d);
+        if ((threadIdx.x & 63) == 0 && tsum) atomicAdd(&a.counters[0], tsum);
+    }
     if (c == 0) {                                            // per-call tier counters -> running totals
         a.counters[4] += a.counters[1];
         a.counters[5] += a.counters[2];
         a.counters[6] += a.counters[3];
-        a.counters[1] = 0ull; a.counters[2] = 0ull; a.counters[3] = 0ull;
+        a.counters[1] = 0ull; a.counters[2] = 0ull; a.counters[3] = 0ull; a.counters[7] = 0ull;
     }
     if (c >= a.n) return;
     const double *S = a.sums + (size_t)c * FS_NACC;
@@ -408,9 +504,12 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
 }
 
 template <int THREADS>
-size_t lds_bytes(int hash_bits, bool global_table)
+size_t lds_bytes(int hash_bits, bool global_table, int n_chunks, int *n_groups)
 {
-    return sizeof(uint32_t) * (Lds<THREADS>::fixed_words + (global_table ? 0 : ((size_t)1 << hash_bits)));
+    constexpr int WAVES = THREADS / 64;
+    *n_groups = (n_chunks + WAVES * 64 - 1) / (WAVES * 64);
+    const size_t mask_words = 2 * (size_t)WAVES * *n_groups + ((2 * WAVES * *n_groups) & 2);   // table stays 16-byte aligned
+    return sizeof(uint32_t) * (Lds<THREADS>::fixed_words + mask_words + (global_table ? 0 : ((size_t)1 << hash_bits)));
 }
 
 template <typename K>
@@ -424,21 +523,23 @@ hipError_t allow_lds(K kernel, size_t bytes)
 #define FS_T1_THREADS 512
 #define FS_T2_THREADS 1024
 
-hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s)
+hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
-    if (a.n <= 0) return hipSuccess;
-    const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false);
+    if (a0.n <= 0) return hipSuccess;
+    FsFimArgs a = a0;
+    const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
     hipError_t e = allow_lds(fs_fim_kernel<FS_T1_THREADS>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fs_fim_kernel<FS_T1_THREADS>, dim3(a.n), dim3(FS_T1_THREADS), lds, s, a);
     return hipGetLastError();
 }
 
-hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s)
+hipError_t fs_launch_fim_overflow(const FsFimArgs &a0, int pool, hipStream_t s)
 {
-    if (a.n <= 0) return hipSuccess;
+    if (a0.n <= 0) return hipSuccess;
+    FsFimArgs a = a0;
     if (a.hash_bits2 > a.hash_bits) {
-        const size_t lds2 = lds_bytes<FS_T2_THREADS>(a.hash_bits2, false);
+        const size_t lds2 = lds_bytes<FS_T2_THREADS>(a.hash_bits2, false, a.n_chunks, &a.n_groups);
         hipError_t e = allow_lds(fs_fim_tier2_kernel<FS_T2_THREADS>, lds2);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(fs_fim_tier2_kernel<FS_T2_THREADS>, dim3(a.n < 256 ? a.n : 256), dim3(FS_T2_THREADS), lds2, s, a);
@@ -446,7 +547,7 @@ hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s)
         if (e != hipSuccess) return e;
     }
     const int blocks = a.n < pool ? a.n : pool;
-    const size_t lds3 = lds_bytes<FS_T2_THREADS>(0, true);
+    const size_t lds3 = lds_bytes<FS_T2_THREADS>(0, true, a.n_chunks, &a.n_groups);
     hipLaunchKernelGGL(fs_fim_tier3_kernel<FS_T2_THREADS>, dim3(blocks), dim3(FS_T2_THREADS), lds3, s, a);
     return hipGetLastError();
 }

@@ -49,7 +49,9 @@ struct FsFimArgs {
     const float *lx, *ly, *lz;
     const float *spheres;      // [n_chunks][4]
     int32_t n_chunks;
+    int32_t n_groups;          // passes of (waves x 64) chunks per workgroup; set by the launcher per kernel configuration
     int32_t cull;              // 0: every chunk is tested (brute force)
+    int32_t ablate;            // development only (option "fim.ablate"): bit mask of stages to skip, results become wrong
     // dense lookup table indexed by the integer voxel lattice
     const float *table;        // [tx][ty][tz], NaN = absent
     int32_t jx0, jy0, jz0;     // lattice index of table[0][0][0]
@@ -57,6 +59,8 @@ struct FsFimArgs {
     double inv_step;           // 1 / (double)0.3f  (FisherInfoManager.hpp:119)
     float inv_step_f;          // (float)inv_step, fast path of the voxel index
     const float *factor;       // crowding factor by rank, [FS_FACTOR_N]; rank >= FS_FACTOR_N -> 0
+    float fac1, fac2, fac3, fac4;   // factor[1..4]
+    int32_t table_full;        // 1: no NaN inside the table box (true for every generated table)
     // visibility
     float maxd2;               // (float)(max_dist^2)
     float cos2;                // c*c, c = (float)cos(max_angle)
@@ -74,6 +78,9 @@ struct FsFimArgs {
     int32_t *n_visible, *n_voxels;
     double *sums;              // [n][18] reduced per-candidate sums (info, 15 FIM block sums, n_visible, n_voxels)
     uint32_t *overflow;        // [n] tier that must re-score the candidate (0 = done)
+    unsigned long long *dbg;   // development only: [n][8] workgroup duration per tier (100 MHz ticks) + phase stamps (shader clocks), or nullptr
+    int32_t *flagged;          // [2][n] work lists: candidates tier 1 / tier 2 hand to the next tier
+    uint32_t *tested;          // [n] landmark tests spent on the candidate (all tiers); zeroed by the finish kernel
     unsigned long long *counters;   // [8]: 0 landmarks tested, 1..3 per-call tier failures, 4..6 their running totals
     // hash tables
     int32_t hash_bits;         // tier 1 (LDS, 512-thread workgroups)
