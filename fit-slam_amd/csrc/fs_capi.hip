@@ -110,6 +110,10 @@ struct fs_ctx {
     DevBuf<fs_record> d_records;
     void *rank_scratch = nullptr;
     size_t rank_scratch_bytes = 0;
+    void *sort_scratch = nullptr;
+    size_t sort_scratch_bytes = 0;
+    DevBuf<int32_t> d_perm;
+    bool opt_sort = true;
 
     // timing
     bool timing = false;
@@ -474,6 +478,8 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_info.release(); c->d_trace.release(); c->d_logdet.release(); c->d_fim21.release(); c->d_Rt.release();
     c->d_overflow.release(); c->d_tested.release(); c->d_flagged.release(); c->d_records.release();
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
+    if (c->sort_scratch) (void)hipFree(c->sort_scratch);
+    c->d_perm.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -659,6 +665,18 @@ int fs_max_arrival(fs_ctx *c, double *max_value, double *max_gt, double *min_gt)
     return FS_OK;
 }
 
+// Spatial processing order for the ray-march kernel (outputs stay in list order).  Small lists are not worth a sort.
+static int maybe_sort(fs_ctx *c, FsRayArgs &a)
+{
+    a.perm = nullptr;
+    if (!c->opt_sort || a.n < 2048) return FS_OK;
+    FS_HIP(c, c->d_perm.ensure(a.n));
+    ScopedTimer t(c, 4);
+    FS_HIP(c, fs_launch_sort_candidates(a.n, a.goal, a.grid, c->d_perm.p, &c->sort_scratch, &c->sort_scratch_bytes, c->stream));
+    a.perm = c->d_perm.p;
+    return FS_OK;
+}
+
 static int upload_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *fsize,
                              const uint8_t *black, const uint8_t *achin)
 {
@@ -706,6 +724,8 @@ int fs_score_arrival(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t
     a.ray_counts = ray_counts ? c->d_raycounts.p : nullptr;
     a.arrival = c->d_arrival.p; a.argmax = c->d_argmax.p; a.status = c->d_status.p;
     a.yaw = c->d_yaw.p; a.achievable = c->d_ach.p;
+    rc = maybe_sort(c, a);
+    if (rc) return rc;
     {
         ScopedTimer t(c, 0);
         FS_HIP(c, fs_launch_raymarch(a, c->stream));
@@ -813,6 +833,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
 {
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.ablate") == 0) { c->opt_ablate = (int)value; return FS_OK; }   // development only
     if (std::strcmp(key, "fim.debug") == 0) { c->opt_debug = value != 0.0; return FS_OK; }    // development only
     return fail(c, FS_E_INVALID, "unknown option %s", key);
@@ -1009,6 +1030,8 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     ra.ray_counts = nullptr;
     ra.arrival = c->d_arrival.p; ra.argmax = c->d_argmax.p; ra.status = c->d_status.p;
     ra.yaw = c->d_yaw.p; ra.achievable = c->d_ach.p;
+    rc = maybe_sort(c, ra);
+    if (rc) return rc;
     {
         ScopedTimer t(c, 0);
         FS_HIP(c, fs_launch_raymarch(ra, c->stream));

@@ -35,6 +35,7 @@ struct FsRayArgs {
     const int32_t *frontier_size;   // or nullptr
     const uint8_t *blacklisted;     // or nullptr
     const uint8_t *achievable_in;   // or nullptr
+    const int32_t *perm;            // spatial processing order (candidate ids) or nullptr; outputs stay in list order
     // outputs (device)
     int32_t *ray_counts;       // [n][n_elev][n_yaw] or nullptr
     int32_t *arrival, *argmax, *status;
@@ -110,6 +111,8 @@ struct FsPackArgs {
 
 // launchers (defined in the .hip files)
 hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s);
+hipError_t fs_launch_sort_candidates(int32_t n, const double *d_goal, const FsGridDev &grid, int32_t *d_perm,
+                                    void **scratch, size_t *scratch_bytes, hipStream_t s);
 hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);

@@ -129,8 +129,14 @@ void fs_raymarch_kernel(const FsRayArgs a)
     extern __shared__ int fs_ray_lds[];          // [FS_RAY_WAVES][n_yaw] per-yaw sums over the elevation rings
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * FS_RAY_WAVES + wave;
-    const bool active = c < a.n;
+    // Workgroups are dealt round-robin over the 8 XCDs (block b -> XCD b % 8), each with its own L2.  With the
+    // candidate list in spatial (Morton) order, give every XCD a contiguous run of it so that neighbouring fans
+    // share cache lines in ONE L2: position p of the sorted list is served by block (p % per) * 8 + p / per.
+    const int per = (int)(gridDim.x >> 3);
+    const int slot_block = a.perm ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int slot = slot_block * FS_RAY_WAVES + wave;
+    const bool active = slot < a.n;
+    const int c = active ? (a.perm ? a.perm[slot] : slot) : 0;
     int *ysum = fs_ray_lds + wave * a.n_yaw;
     const int n_rays = a.n_yaw * a.n_elev;
 
@@ -256,7 +262,8 @@ __global__ void fs_pack_kernel(const FsPackArgs p)
 hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
 {
     if (a.n <= 0) return hipSuccess;
-    const int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
+    int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
+    if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
     hipLaunchKernelGGL(fs_raymarch_kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();

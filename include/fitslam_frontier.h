@@ -105,12 +105,13 @@ int  fs_synchronize(fs_ctx *ctx);
 
 /* Per-kernel device time.  With timing enabled every kernel launch is bracketed by hipEvents on
  * the context's stream; fs_kernel_time returns and resets the accumulated (ms, launches) of
- * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM overflow pass, 3 utility/rank. */
+ * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM larger-table tiers, 3 utility/rank, 4 candidate sort. */
 int  fs_enable_kernel_timing(fs_ctx *ctx, int enable);
 int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
 
 /* Tuning / diagnostic knobs (no reference counterpart).  Keys: "fim.cull" (default 1): per-chunk
- * bounding-sphere culling of the landmark cloud; 0 tests every landmark (brute force; identical results). */
+ * bounding-sphere culling of the landmark cloud; 0 tests every landmark (brute force; identical results).
+ * "ray.sort" (default 1): ray-march candidates in Morton order of their goal cell (lists of >= 2048). */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
 /* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
  * 4/5/6 = candidates re-scored by the second / third hash-table tier / unresolved (always 0). */
