@@ -271,6 +271,7 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
 
     // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
     // next chunk's landmarks prefetched into registers while the current one is processed.
+    if (a.dbg) st2 = clock64();
     for (int g = 0; g < a.n_groups && !skip_tier; ++g) {
         const int g0 = g * STRIDE;
         unsigned long long mask = masks[g];
@@ -282,20 +283,23 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
             // the waves makes the prefix representative): a table that clearly will not fit is handed on early
             if (g > 0 && (long long)(*v_nvox) * a.n_chunks > (long long)nvox_limit * g0 * 5 / 4) { overflow = true; *v_overflow = 1; break; }
         }
-        int cur = -1;
-        if (mask) { cur = g0 + __builtin_ctzll(mask) * WAVES + wave; mask &= mask - 1ull; }
-        float wx = 0.f, wy = 0.f, wz = 0.f;
-        if (cur >= 0) { const int l = cur * 64 + lane; wx = LX[l]; wy = LY[l]; wz = LZ[l]; }
-        while (cur >= 0) {
-            int nxt = -1;
-            float nx = 0.f, ny = 0.f, nz = 0.f;
-            if (mask) {
-                nxt = g0 + __builtin_ctzll(mask) * WAVES + wave; mask &= mask - 1ull;
-                const int l = nxt * 64 + lane;
-                nx = LX[l]; ny = LY[l]; nz = LZ[l];
-            }
+        // two chunks in flight ahead of the one being processed
+        auto pop = [&]() -> int {
+            if (!mask) return -1;
+            const int id = g0 + __builtin_ctzll(mask) * WAVES + wave;
+            mask &= mask - 1ull;
+            return id;
+        };
+        int c0 = pop(), c1 = pop();
+        float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
+        if (c0 >= 0) { const int l = c0 * 64 + lane; x0 = LX[l]; y0 = LY[l]; z0 = LZ[l]; }
+        if (c1 >= 0) { const int l = c1 * 64 + lane; x1 = LX[l]; y1 = LY[l]; z1 = LZ[l]; }
+        while (c0 >= 0) {
+            const int c2 = pop();
+            float x2 = 0.f, y2 = 0.f, z2 = 0.f;
+            if (c2 >= 0) { const int l = c2 * 64 + lane; x2 = LX[l]; y2 = LY[l]; z2 = LZ[l]; }
             // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
-            const float dx = wx - t[0], dy = wy - t[1], dz = wz - t[2];
+            const float dx = x0 - t[0], dy = y0 - t[1], dz = z0 - t[2];
             const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
             const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
             const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
@@ -315,7 +319,9 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
                     qcount -= 64;                                  // take the newest 64: the remainder stays in place
                     const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
                     // ---- 4. score
+                    const unsigned long long sc0 = a.dbg ? clock64() : 0ull;
                     const bool opened = score_visible(a, table, lfac, bits, max_probe, ex, ey, ez, acc, overflow);
+                    if (a.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sc_clk += clock64() - sc0; sc_n += 1; }
                     const unsigned long long om = __ballot(opened);
                     if (!GLOBAL_TABLE && om != 0ull) {
                         int total = 0;
@@ -325,9 +331,11 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
                     if (__any(overflow)) *v_overflow = 1;
                 }
             }
-            cur = nxt; wx = nx; wy = ny; wz = nz;
+            c0 = c1; x0 = x1; y0 = y1; z0 = z1;
+            c1 = c2; x1 = x2; y1 = y2; z1 = z2;
         }
     }
+    if (a.dbg) st3 = clock64();
     if (skip_tier) qcount = 0;
     // flush the queue remainder
     if (lane < qcount) score_visible(a, table, lfac, bits, max_probe, qx[lane], qy[lane], qz[lane], acc, overflow);
