@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "fs_abi_version", "fs_ctx_create", "fs_ctx_destroy", "fs_last_error", "fs_synchronize",
     "fs_enable_kernel_timing", "fs_kernel_time", "fs_set_option", "fs_get_counter",
     "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_max_arrival", "fs_set_arrival_limits",
-    "fs_score_arrival",
+    "fs_score_arrival", "fs_trace_segments",
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim",
     "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_selftest_fp64",
@@ -83,6 +83,7 @@ def load_library(build: bool = True):
     L.fs_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
     L.fs_set_arrival_limits.argtypes = [vp, dbl, dbl]
     L.fs_score_arrival.argtypes = [vp, i32] + [vp] * 10
+    L.fs_trace_segments.argtypes = [vp, i32, vp, vp, dbl, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.fs_upload_landmarks.argtypes = [vp, vp, i32]
     L.fs_lookup_generate.argtypes = [vp, vp]
     L.fs_lookup_load.argtypes = [vp, C.c_char_p]
@@ -204,6 +205,16 @@ class FrontierScorer:
         self._check(self._L.fs_score_arrival(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(rc_arr),
                                              _p(arrival), _p(argmax), _p(yaw), _p(ach), _p(status)))
         return dict(ray_counts=rc_arr, arrival=arrival, argmax=argmax, yaw=yaw, achievable=ach, status=status)
+
+    def trace_segments(self, start_xyz, end_xyz, max_length_cells, obst=(253, 254), trace=(0, 255)):
+        a = np.ascontiguousarray(start_xyz, dtype=np.float64).reshape(-1, 3)
+        b = np.ascontiguousarray(end_xyz, dtype=np.float64).reshape(-1, 3)
+        n = a.shape[0]
+        ok = np.zeros(n, np.uint8); hit = np.zeros(n, np.uint8)
+        traced = np.zeros(n, np.int32); unknown = np.zeros(n, np.int32); allc = np.zeros(n, np.int32)
+        self._check(self._L.fs_trace_segments(self._h, n, _p(a), _p(b), float(max_length_cells), int(obst[0]), int(obst[1]),
+                                              int(trace[0]), int(trace[1]), _p(ok), _p(traced), _p(hit), _p(unknown), _p(allc)))
+        return dict(ok=ok, traced=traced, hit=hit, unknown=unknown, all=allc)
 
     # -- Fisher information
     def upload_landmarks(self, xyz):

@@ -740,6 +740,38 @@ int fs_score_arrival(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t
     return FS_OK;
 }
 
+int fs_trace_segments(fs_ctx *c, int32_t n, const double *start_xyz, const double *end_xyz, double max_length_cells,
+                      int32_t obst_min, int32_t obst_max, int32_t trace_min, int32_t trace_max,
+                      uint8_t *ok, int32_t *traced, uint8_t *hit, int32_t *unknown, int32_t *all)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
+    if (n < 0 || (n > 0 && (!start_xyz || !end_xyz || !ok || !traced || !hit || !unknown || !all))) return fail(c, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    DevBuf<double> d_s, d_e;
+    DevBuf<uint8_t> d_ok, d_hit;
+    DevBuf<int32_t> d_tr, d_un, d_all;
+    FS_HIP(c, d_s.ensure((size_t)n * 3)); FS_HIP(c, d_e.ensure((size_t)n * 3));
+    FS_HIP(c, d_ok.ensure(n)); FS_HIP(c, d_hit.ensure(n)); FS_HIP(c, d_tr.ensure(n)); FS_HIP(c, d_un.ensure(n)); FS_HIP(c, d_all.ensure(n));
+    FS_HIP(c, hipMemcpyAsync(d_s.p, start_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(d_e.p, end_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    FsSegArgs a{};
+    a.grid = FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res};
+    a.n = n; a.start = d_s.p; a.end = d_e.p; a.max_length = max_length_cells;
+    a.obst_min = obst_min; a.obst_max = obst_max; a.trace_min = trace_min; a.trace_max = trace_max;
+    a.ok = d_ok.p; a.hit = d_hit.p; a.traced = d_tr.p; a.unknown = d_un.p; a.all = d_all.p;
+    FS_HIP(c, fs_launch_segments(a, c->stream));
+    FS_HIP(c, hipMemcpyAsync(ok, d_ok.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(hit, d_hit.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(traced, d_tr.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(unknown, d_un.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipMemcpyAsync(all, d_all.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    d_s.release(); d_e.release(); d_ok.release(); d_hit.release(); d_tr.release(); d_un.release(); d_all.release();
+    return FS_OK;
+}
+
 // ------------------------------------------------------------------ Fisher information
 
 int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)

@@ -43,6 +43,18 @@ struct FsRayArgs {
     uint8_t *achievable;
 };
 
+// ---- generic segment tracing (getTracedCells + a RayTracedCells visitor per segment)
+struct FsSegArgs {
+    FsGridDev grid;
+    int32_t n;
+    const double *start, *end;      // [n][3]
+    double max_length;              // cells (the reference passes it as double)
+    int32_t obst_min, obst_max, trace_min, trace_max;
+    uint8_t *ok, *hit;
+    int32_t *traced, *unknown, *all;
+};
+hipError_t fs_launch_segments(const FsSegArgs &a, hipStream_t s);
+
 // ---- FIM kernel arguments ---------------------------------------------------------------------
 struct FsFimArgs {
     // landmarks: Morton-ordered SoA, n_chunks chunks of 64 (the tail padded with far-away sentinels),

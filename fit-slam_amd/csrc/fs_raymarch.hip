@@ -227,6 +227,55 @@ void fs_raymarch_kernel(const FsRayArgs a)
     }
 }
 
+// One lane per segment: getTracedCells(sx, sy, wx, wy, visitor, max_length, costmap) for arbitrary end points
+// (DEP/src/Helpers.cpp:32-96) with every RayTracedCells accessor (Helpers.hpp:83-101).  Unlike the arrival
+// fan the walk never stops early: unknown_cells_ and all_cells_count_ keep counting behind an obstacle.
+__global__ void fs_segments_kernel(const FsSegArgs s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    FsRayArgs a{};
+    a.grid = s.grid;
+    const FsGridDev &g = s.grid;
+    uint32_t x1, y1, z1, x0, y0, z0;
+    const double sx = s.start[3 * i], sy = s.start[3 * i + 1], sz = s.start[3 * i + 2];
+    const double wx = s.end[3 * i], wy = s.end[3 * i + 1], wz = s.end[3 * i + 2];
+    int traced = 0, unknown = 0, all = 0;
+    bool hit = false, ok = false;
+    if (world_to_map(g, wx, wy, wz, x1, y1, z1) && world_to_map(g, sx, sy, sz, x0, y0, z0)) {
+        ok = true;
+        const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
+        const long long d2 = (long long)dx * dx + (long long)dy * dy + (long long)dz * dz;
+        const double dist = sqrt((double)d2);
+        const uint32_t nx = (uint32_t)g.nx, ny = (uint32_t)g.ny;
+        RayWalk w;
+        w.offset = (z0 * ny + y0) * nx + x0;
+        const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
+        const int odx = sign_ref(dx), ody = sign_ref(dy) * (int)nx, odz = sign_ref(dz) * (int)(nx * ny);
+        const double q = s.max_length / dist;
+        const double scale = (dist == 0.0) ? 1.0 : ((q < 1.0) ? q : 1.0);
+        if (adx >= ady && adx >= adz) { w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz; }
+        else if (ady >= adz) { w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz; }
+        else { w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody; }
+        w.err_b = w.err_c = (int)(w.abs_da / 2);
+        const uint32_t max_steps = (uint32_t)(scale * (double)w.abs_da);
+        const uint32_t end = max_steps < w.abs_da ? max_steps : w.abs_da;
+        const uint32_t total = nx * ny * (uint32_t)g.nz;
+        for (uint32_t v = 0; v <= end; ++v) {
+            if (w.offset < total) {
+                const int c = (int)g.cells[w.offset];
+                ++all;                                                        // Helpers.hpp:62
+                if (c <= s.trace_max && c >= s.trace_min && !hit) ++traced;   // :64-67
+                if (c >= s.obst_min && c <= s.obst_max) hit = true;           // :68-71
+                if (c == 255) ++unknown;                                      // :72-75
+            }
+            walk_step(w);
+        }
+    }
+    s.ok[i] = ok; s.hit[i] = hit;
+    s.traced[i] = traced; s.unknown[i] = unknown; s.all[i] = all;
+}
+
 __global__ void fs_selftest_kernel(int32_t max_abs, double *out_sqrt, double *out_div)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,6 +315,13 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
     if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
     hipLaunchKernelGGL(fs_raymarch_kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t fs_launch_segments(const FsSegArgs &a, hipStream_t s)
+{
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fs_segments_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

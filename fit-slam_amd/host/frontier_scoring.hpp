@@ -420,6 +420,30 @@ private:
     std::unordered_map<const Frontier *, bool> frontier_blacklist_;
 };
 
+// FrontierRoadMap::isConnectable (DEP/src/planners/FrontierRoadmap.cpp:716-737) for a batch of node pairs: visitor
+// (253,254,0,255); connectable iff the trace succeeded, hit no obstacle and saw at most
+// 0.3 * RADIUS_TO_DECIDE_EDGES / resolution unknown cells.
+inline std::vector<bool> isConnectable(ScoringContext &ctx, const Costmap2D &costmap,
+                                       const std::vector<std::pair<FrontierPtr, FrontierPtr>> &pairs,
+                                       double max_connection_length, double radius_to_decide_edges)
+{
+    const int32_t n = (int32_t)pairs.size();
+    std::vector<double> s(3 * (size_t)n), e(3 * (size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        const Point &a = pairs[i].first->getGoalPoint(), &b = pairs[i].second->getGoalPoint();
+        s[3 * i] = a.x; s[3 * i + 1] = a.y; s[3 * i + 2] = a.z; e[3 * i] = b.x; e[3 * i + 1] = b.y; e[3 * i + 2] = b.z;
+    }
+    std::vector<uint8_t> ok(n), hit(n);
+    std::vector<int32_t> traced(n), unknown(n), all(n);
+    const unsigned int max_length = max_connection_length / costmap.getResolution();
+    ctx.check(fs_trace_segments(ctx.get(), n, s.data(), e.data(), (double)max_length, 253, 254, 0, 255, ok.data(), traced.data(),
+                                hit.data(), unknown.data(), all.data()), "fs_trace_segments");
+    std::vector<bool> out(n);
+    for (int32_t i = 0; i < n; ++i)
+        out[i] = ok[i] && !hit[i] && !(unknown[i] > radius_to_decide_edges / costmap.getResolution() * 0.3);
+    return out;
+}
+
 // DEP/include/.../CostAssigner.hpp:43-59
 struct GetFrontierCostsRequest
 {

@@ -153,6 +153,18 @@ int fs_score_arrival(fs_ctx *ctx, int32_t n, const double *goal_xyz, const int32
                      int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
                      uint8_t *achievable, int32_t *status);
 
+/* Replaces bool getTracedCells(double sx, double sy, double wx, double wy, RayTracedCells&, double max_length,
+ * Costmap2D*) (DEP/include/.../Helpers.hpp:125-126, DEP/src/Helpers.cpp:32-96) with a RayTracedCells visitor
+ * (Helpers.hpp:20-111) for a batch of arbitrary segments — the form FrontierRoadMap::isConnectable
+ * (DEP/src/planners/FrontierRoadmap.cpp:716-737, visitor (253,254,0,255)) and the recovery controller
+ * (fit_slam2_recovery/src/recovery_controller.cpp:78-88, visitor (256,256,0,255)) use.
+ *   start_xyz, end_xyz [n][3]; max_length_cells as the reference passes it (a double, in cells)
+ *   ok [n]      the bool return (false: a worldToMap failed)        traced [n]  getCells().size()
+ *   hit [n]     hasHitObstacle()     unknown [n] getNumUnknown()     all [n]     getCellsSize() */
+int fs_trace_segments(fs_ctx *ctx, int32_t n, const double *start_xyz, const double *end_xyz, double max_length_cells,
+                      int32_t obst_min, int32_t obst_max, int32_t trace_min, int32_t trace_max,
+                      uint8_t *ok, int32_t *traced, uint8_t *hit, int32_t *unknown, int32_t *all);
+
 /* ---------------------------------------------------------------- Fisher information */
 
 /* Replaces the per-query service response `map_points` (FIP/src/.../FisherInfoManager.cpp:60-88)

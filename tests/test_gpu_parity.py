@@ -288,3 +288,26 @@ def test_fim_culling_is_exact(fs, oracle, scorer, ref_table):
     got = scorer.score_fim(bad)
     want = oracle.pose_information(ref_table, w.landmarks, bad, 14.0, 1.0)
     np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
+
+
+def test_trace_segments_matches_oracle(fs, oracle, scorer):
+    """getTracedCells + RayTracedCells accessors for arbitrary segments (roadmap edge test, recovery controller)."""
+    rng = np.random.default_rng(23)
+    for w, is3d in ((fs.synth.make_small_2d(41, n=128, n_cand=8), False), (fs.synth.make_workload("C1", n_cand=8), True)):
+        scorer.upload_grid(w.cells, w.origin, w.resolution)
+        G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
+        nz, ny, nx = w.cells.shape
+        lo = np.array(w.origin); hi = lo + np.array([nx, ny, nz]) * w.resolution
+        n = 600
+        a = rng.uniform(lo - 0.1, hi + 0.1, size=(n, 3)); b = a + rng.normal(scale=1.5, size=(n, 3))
+        if not is3d:
+            a[:, 2] = 0.0; b[:, 2] = 0.0
+        b[:20] = a[:20]                                           # zero-length segments: one visit
+        for obst, trace, L in (((253, 254), (0, 255), 122), ((256, 256), (0, 255), 80), ((240, 254), (255, 255), 40)):
+            got = scorer.trace_segments(a, b, L, obst=obst, trace=trace)
+            for i in range(n):
+                r = oracle.trace_ray(G, a[i], b[i], L, obst=obst, trace=trace, faithful=True)
+                assert bool(got["ok"][i]) == r["ok"]
+                if r["ok"]:
+                    assert (got["traced"][i], bool(got["hit"][i]), got["unknown"][i], got["all"][i]) == \
+                        (r["traced"], r["hit"], r["unknown"], r["all"]), i
