@@ -21,7 +21,7 @@ FS_MAX_ELEV = 16
 EXPORTED_SYMBOLS = [
     "fs_abi_version", "fs_ctx_create", "fs_ctx_destroy", "fs_last_error", "fs_synchronize",
     "fs_enable_kernel_timing", "fs_kernel_time", "fs_set_option", "fs_get_counter",
-    "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_max_arrival", "fs_set_arrival_limits",
+    "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_upload_grid_bricks", "fs_frontier_cells", "fs_max_arrival", "fs_set_arrival_limits",
     "fs_score_arrival", "fs_trace_segments",
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim",
@@ -80,6 +80,8 @@ def load_library(build: bool = True):
     L.fs_set_ray_params.argtypes = [vp, C.POINTER(RayParamsC)]
     L.fs_ray_fan_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.fs_upload_grid.argtypes = [vp, vp, i32, i32, i32, C.POINTER(dbl * 3), dbl]
+    L.fs_upload_grid_bricks.argtypes = [vp, i32, i32, i32, C.POINTER(dbl * 3), dbl, C.c_uint8, i64, vp, vp]
+    L.fs_frontier_cells.argtypes = [vp, i32, vp, C.POINTER(i64)]
     L.fs_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
     L.fs_set_arrival_limits.argtypes = [vp, dbl, dbl]
     L.fs_score_arrival.argtypes = [vp, i32] + [vp] * 10
@@ -184,6 +186,20 @@ class FrontierScorer:
         nz, ny, nx = c.shape
         o = (C.c_double * 3)(*[float(v) for v in origin])
         self._check(self._L.fs_upload_grid(self._h, _p(c), nx, ny, nz, C.byref(o), float(resolution)))
+
+    def upload_grid_bricks(self, shape_zyx, origin, resolution, brick_xyz, brick_cells, default_value=255):
+        nz, ny, nx = shape_zyx
+        xyz = np.ascontiguousarray(brick_xyz, dtype=np.int32).reshape(-1, 3)
+        cells = np.ascontiguousarray(brick_cells, dtype=np.uint8).reshape(-1, 512)
+        o = (C.c_double * 3)(*[float(v) for v in origin])
+        self._check(self._L.fs_upload_grid_bricks(self._h, nx, ny, nz, C.byref(o), float(resolution), int(default_value),
+                                                  xyz.shape[0], _p(xyz), _p(cells)))
+
+    def frontier_cells(self, shape_zyx, lethal_threshold=160, want_mask=True):
+        mask = np.zeros(shape_zyx, dtype=np.uint8) if want_mask else None
+        n = C.c_int64()
+        self._check(self._L.fs_frontier_cells(self._h, int(lethal_threshold), _p(mask), C.byref(n)))
+        return mask, n.value
 
     def max_arrival(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()

@@ -76,9 +76,6 @@ struct fs_ctx {
     int32_t m = 0, n_chunks = 0;
     DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
     bool opt_cull = true;
-    int opt_ablate = 0;
-    bool opt_debug = false;
-    DevBuf<unsigned long long> d_dbg;
     DevBuf<unsigned long long> d_counters;
 
     // lookup table
@@ -376,7 +373,6 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     a.spheres = c->d_spheres.p;
     a.n_chunks = c->n_chunks;
     a.cull = c->opt_cull ? 1 : 0;
-    a.ablate = c->opt_ablate;
     a.table = c->d_table.p;
     a.jx0 = c->jx0; a.jy0 = c->jy0; a.jz0 = c->jz0;
     a.tx = c->tx; a.ty = c->ty; a.tz = c->tz;
@@ -610,6 +606,65 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
     c->res = resolution;
     c->have_grid = true;
     c->max_gt = 0.0; c->min_gt = 0.0;
+    return FS_OK;
+}
+
+int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const double origin_xyz[3], double resolution,
+                          uint8_t default_value, int64_t n_bricks, const int32_t *brick_xyz, const uint8_t *brick_cells)
+{
+    if (!c || !origin_xyz || n_bricks < 0 || (n_bricks > 0 && (!brick_xyz || !brick_cells))) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
+    if ((nx & 7) || (ny & 7) || (nz & 7)) return fail(c, FS_E_INVALID, "brick upload needs dimensions that are multiples of 8");
+    const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
+    if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
+    FS_HIP(c, c->d_cells.ensure((size_t)total));
+    FS_HIP(c, hipMemsetAsync(c->d_cells.p, default_value, (size_t)total, c->stream));
+    if (n_bricks > 0) {
+        DevBuf<int32_t> d_xyz;
+        DevBuf<uint8_t> d_bc;
+        DevBuf<int32_t> d_bad;
+        FS_HIP(c, d_xyz.ensure((size_t)n_bricks * 3)); FS_HIP(c, d_bc.ensure((size_t)n_bricks * 512)); FS_HIP(c, d_bad.ensure(1));
+        FS_HIP(c, hipMemsetAsync(d_bad.p, 0, 4, c->stream));
+        FS_HIP(c, hipMemcpyAsync(d_xyz.p, brick_xyz, sizeof(int32_t) * 3 * (size_t)n_bricks, hipMemcpyHostToDevice, c->stream));
+        FS_HIP(c, hipMemcpyAsync(d_bc.p, brick_cells, (size_t)n_bricks * 512, hipMemcpyHostToDevice, c->stream));
+        FS_HIP(c, fs_launch_brick_scatter(n_bricks, d_xyz.p, d_bc.p, c->d_cells.p, nx, ny, nz, d_bad.p, c->stream));
+        int32_t bad = 0;
+        FS_HIP(c, hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(c, hipStreamSynchronize(c->stream));
+        d_xyz.release(); d_bc.release(); d_bad.release();
+        if (bad) { c->have_grid = false; return fail(c, FS_E_INVALID, "a brick lies outside the grid"); }
+    }
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    c->nx = nx; c->ny = ny; c->nz = nz;
+    c->origin[0] = origin_xyz[0]; c->origin[1] = origin_xyz[1]; c->origin[2] = origin_xyz[2];
+    c->res = resolution;
+    c->have_grid = true;
+    c->max_gt = 0.0; c->min_gt = 0.0;
+    return FS_OK;
+}
+
+int fs_frontier_cells(fs_ctx *c, int32_t lethal_threshold, uint8_t *mask, int64_t *count)
+{
+    if (!c || !count) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
+    const size_t total = (size_t)c->nx * c->ny * c->nz;
+    DevBuf<uint8_t> d_mask;
+    DevBuf<unsigned long long> d_count;
+    if (mask) FS_HIP(c, d_mask.ensure(total));
+    FS_HIP(c, d_count.ensure(1));
+    FS_HIP(c, hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), c->stream));
+    {
+        ScopedTimer t(c, 5);
+        FS_HIP(c, fs_launch_frontier_cells(c->d_cells.p, c->nx, c->ny, c->nz, lethal_threshold, mask ? d_mask.p : nullptr, d_count.p, c->stream));
+    }
+    unsigned long long n = 0;
+    FS_HIP(c, hipMemcpyAsync(&n, d_count.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    if (mask) FS_HIP(c, hipMemcpyAsync(mask, d_mask.p, total, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    d_mask.release(); d_count.release();
+    *count = (int64_t)n;
     return FS_OK;
 }
 
@@ -866,18 +921,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "fim.ablate") == 0) { c->opt_ablate = (int)value; return FS_OK; }   // development only
-    if (std::strcmp(key, "fim.debug") == 0) { c->opt_debug = value != 0.0; return FS_OK; }    // development only
     return fail(c, FS_E_INVALID, "unknown option %s", key);
-}
-
-int fs_debug_fetch(fs_ctx *c, int32_t n, uint64_t *out)
-{
-    if (!c || !out || !c->d_dbg.p) return FS_E_INVALID;
-    FS_HIP(c, hipSetDevice(c->device));
-    FS_HIP(c, hipMemcpyAsync(out, c->d_dbg.p, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipStreamSynchronize(c->stream));
-    return FS_OK;
 }
 
 int fs_get_counter(fs_ctx *c, int which, int64_t *value, int reset)
@@ -985,12 +1029,6 @@ static int run_fim(fs_ctx *c, FsFimArgs &a)
     a.sums = c->d_sums.p;
     a.tested = c->d_tested.p;
     a.flagged = c->d_flagged.p;
-    a.dbg = nullptr;
-    if (c->opt_debug) {
-        FS_HIP(c, c->d_dbg.ensure((size_t)a.n * 8));
-        FS_HIP(c, hipMemsetAsync(c->d_dbg.p, 0, (size_t)a.n * 8 * sizeof(unsigned long long), c->stream));
-        a.dbg = c->d_dbg.p;
-    }
     {
         ScopedTimer t(c, 1);
         FS_HIP(c, fs_launch_fim(a, c->stream));

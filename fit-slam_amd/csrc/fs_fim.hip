@@ -49,15 +49,12 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
     return (key * 2654435761u) >> (32 - bits);
 }
 
-// find-or-insert `key` and bump its count; returns the landmark's rank in the voxel (1-based),
-// 0 if no slot was found within max_probe.  is_new is set when this call created the voxel entry.
-__device__ __forceinline__ uint32_t table_bump(uint32_t *table, int bits, uint32_t key, uint32_t max_probe, bool &is_new)
+// Generic find-or-insert from probe position h (slow path: collisions).  Returns the rank (1-based), 0 if no slot
+// was found within max_probe probes.
+__device__ __noinline__ uint32_t table_bump_slow(uint32_t *table, uint32_t mask, uint32_t tag, uint32_t h, uint32_t max_probe, bool &is_new)
 {
-    const uint32_t mask = (1u << bits) - 1u;
-    const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
-    uint32_t h = hash_key(key, bits);
-    is_new = false;
-    for (uint32_t probe = 0; probe < max_probe; ++probe) {
+    for (uint32_t probe = 1; probe < max_probe; ++probe) {
+        h = (h + 1u) & mask;
         uint32_t cur = table[h];
         if (cur == 0u) {
             const uint32_t prev = atomicCAS(&table[h], 0u, tag | 1u);
@@ -65,48 +62,54 @@ __device__ __forceinline__ uint32_t table_bump(uint32_t *table, int bits, uint32
             cur = prev;
         }
         if ((cur & ~FS_SLOT_CNT_MASK) == tag) {
-            if ((cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT) return FS_SLOT_CNT_SAT + 1u;   // factor is 0.0f out here
-            const uint32_t old = atomicAdd(&table[h], 1u);
-            return (old & FS_SLOT_CNT_MASK) + 1u;
+            if ((cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT) return FS_SLOT_CNT_SAT + 1u;
+            return (atomicAdd(&table[h], 1u) & FS_SLOT_CNT_MASK) + 1u;
         }
-        h = (h + 1u) & mask;
     }
     return 0u;
 }
 
-// round(x * (1 / corrected_step)) of getVoxelCoordinate (FisherInfoManager.hpp:119-121), exactly.
-// The fp32 product is within |r| * 1.3e-7 of the fp64 one (|r| < 2^10 checked), so away from a .5 boundary
-// the fp32 nearest integer equals the fp64 half-away-from-zero result; next to one, evaluate the fp64 expression.
-__device__ __forceinline__ int voxel_index(float p, double inv_step, float inv_step_f)
-{
-    const float r = p * inv_step_f;
-    const float rn = rintf(r);
-    const float frac = fabsf(r - rn);
-    if (frac < 0.4995f && fabsf(r) < 1024.0f) return (int)rn;     // 5e-4 >> the fp32 product's error bound 1.4e-4
-    return (int)round((double)p * inv_step);
-}
-
-// returns true when this landmark opened a new voxel entry
+// Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch).
+// Written as predicated straight-line code: the scalar unit, not the vector ALU, limited the branchy version.
+// Returns true when this landmark opened a new voxel entry.
 __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
-                                              float px, float py, float pz, Acc &acc, bool &overflow)
+                                              bool active, float px, float py, float pz, Acc &acc, bool &overflow)
 {
-    acc.nvis += 1;
-    if (a.ablate & 1) return false;
-    // dense-table lookup first: its latency overlaps the FIM arithmetic below
-    const int jx = voxel_index(px, a.inv_step, a.inv_step_f) - a.jx0;
-    const int jy = voxel_index(py, a.inv_step, a.inv_step_f) - a.jy0;
-    const int jz = voxel_index(pz, a.inv_step, a.inv_step_f) - a.jz0;
-    const bool in_table = (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
-    const uint32_t key = ((uint32_t)jx * (uint32_t)a.ty + (uint32_t)jy) * (uint32_t)a.tz + (uint32_t)jz;
-    float info_v = __builtin_nanf("");
-    if (in_table) info_v = (a.ablate & 4) ? 2.0f : a.table[key];
+    acc.nvis += active ? 1 : 0;
+    // ---- voxel lattice index: round(x * (1 / corrected_step)) of getVoxelCoordinate (FisherInfoManager.hpp:119-121),
+    // exactly.  The fp32 product is within |r| * 1.3e-7 of the fp64 one (|r| < 2^10 checked), so away from a .5
+    // boundary the fp32 nearest integer equals the fp64 half-away-from-zero result; lanes next to a boundary
+    // (0.1 %) re-evaluate the fp64 expression.
+    const float rx = px * a.inv_step_f, ry = py * a.inv_step_f, rz = pz * a.inv_step_f;
+    const float nx = rintf(rx), ny = rintf(ry), nz = rintf(rz);
+    int jx = (int)nx, jy = (int)ny, jz = (int)nz;
+    const float worst = fmaxf(fmaxf(fabsf(rx - nx), fabsf(ry - ny)), fabsf(rz - nz));
+    const float big = fmaxf(fmaxf(fabsf(rx), fabsf(ry)), fabsf(rz));
+    if (active && !(worst < 0.4995f && big < 1024.0f)) {
+        jx = (int)round((double)px * a.inv_step);
+        jy = (int)round((double)py * a.inv_step);
+        jz = (int)round((double)pz * a.inv_step);
+    }
+    jx -= a.jx0; jy -= a.jy0; jz -= a.jz0;
+    const bool in_table = active && (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
+    const uint32_t key = in_table ? ((uint32_t)jx * (uint32_t)a.ty + (uint32_t)jy) * (uint32_t)a.tz + (uint32_t)jz : 0u;
+    // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
+    const float info_t = a.table[key];
 
-    // unit-weight FIM block sums, F(p) = [[P/n^2, -S/n^2],[S/n^2, P]].  P's diagonal is
-    // formed as a sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector
-    // has no Jacobian.
-    const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
-    if (n2 > 0.0f && !(a.ablate & 8)) {
-        const float q = 1.0f / n2;
+    // ---- first probe of the voxel's hash slot (the reference's pointCount bookkeeping, :296-304)
+    const uint32_t mask = (1u << bits) - 1u;
+    const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
+    const uint32_t h = hash_key(key, bits);
+    // a table without holes (every generated table) lets the update start without waiting for the gathered value
+    bool valid = in_table;
+    if (!a.table_full) valid = valid && (info_t == info_t);
+    uint32_t cur = valid ? table[h] : 0xffffffffu;
+
+    // ---- unit-weight FIM block sums, F(p) = [[P/n^2, -S/n^2],[S/n^2, P]]; P's diagonal as a
+    // sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector has no Jacobian.
+    {
+        const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
+        const float q = (active && n2 > 0.0f) ? 1.0f / n2 : 0.0f;
         const float qx = px * q, qy = py * q, qz = pz * q;
         const float xx = px * qx, yy = py * qy, zz = pz * qz;
         const float v[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
@@ -114,21 +117,27 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         for (int i = 0; i < 6; ++i) { acc.A[i] += v[i]; acc.B[i] += v[i] * q; }
         acc.s[0] += qx; acc.s[1] += qy; acc.s[2] += qz;
     }
-    // A table without holes inside its box (every generated table) lets the hash update start without
-    // waiting for the gathered value; otherwise absent lattice points must be skipped first.
-    if (!in_table) return false;                             // key miss -> NaN -> skipped (:90-94)
-    if (!a.table_full && info_v != info_v) return false;     // absent lattice point
-    bool is_new = false;
-    const uint32_t rank = (a.ablate & 2) ? 1u : table_bump(table, bits, key, max_probe, is_new);
-    if (rank == 0u) { overflow = true; return false; }
-    if (is_new) acc.nvox += 1;                               // occupied_voxel_count_++ (:304)
-    // crowding factor exp(1 - k^0.8): ranks 1..4 from scalar registers, the rest from the table
-    float fac = a.fac1;
-    if (rank > 1u) fac = (rank == 2u) ? a.fac2 : (rank == 3u) ? a.fac3 : (rank == 4u) ? a.fac4
-                       : (rank < FS_FACTOR_N ? lfac[rank] : 0.0f);
-    // :318 — (float)(double information * float factor): the double product of two floats is exact,
-    // so one rounding to float == the fp32 product
-    acc.info += info_v * fac;
+
+    const bool try_cas = valid && cur == 0u;
+    if (try_cas) cur = atomicCAS(&table[h], 0u, tag | 1u);           // returns 0 when this lane created the entry
+    const bool won = try_cas && cur == 0u;
+    const bool match = valid && !won && (cur & ~FS_SLOT_CNT_MASK) == tag;
+    const bool sat = match && (cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT;   // factor is 0.0f out there anyway
+    uint32_t old = 0u;
+    if (match && !sat) old = atomicAdd(&table[h], 1u);
+    uint32_t rank = won ? 1u : (match ? (sat ? FS_SLOT_CNT_SAT + 1u : (old & FS_SLOT_CNT_MASK) + 1u) : 0u);
+    bool is_new = won;
+    const bool unresolved = valid && !won && !match;                  // the slot holds another voxel: keep probing
+    if (unresolved) {
+        rank = table_bump_slow(table, mask, tag, h, max_probe, is_new);
+        if (rank == 0u) overflow = true;
+    }
+    acc.nvox += is_new ? 1 : 0;                                       // occupied_voxel_count_++ (:304)
+    // crowding factor exp(1 - k^0.8) from the LDS copy (entry 0 and everything beyond rank ~340 are 0.0f).
+    // :318 — (float)(double information * float factor): the double product of two floats is exact, so one
+    // rounding to float == the fp32 product.
+    const float fac = lfac[rank < FS_FACTOR_N ? rank : FS_FACTOR_N - 1];
+    acc.info += (valid && rank != 0u) ? info_t * fac : 0.0f;
     return is_new;
 }
 
@@ -170,8 +179,6 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     __shared__ int sh_overflow, sh_nvox, sh_wave_tested[WAVES];
     __shared__ float sh_red[WAVES * FS_NACC];
 
-    const unsigned long long dbg_t0 = a.dbg ? wall_clock64() : 0ull;
-    unsigned long long st2 = 0, st3 = 0, sc_clk = 0, sc_n = 0;
     // ---- pose
     float R[9], t[3];
     if (a.Rt) {
@@ -217,7 +224,6 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
             }
         }
         unsigned long long mask = __ballot(keep);
-        if (a.ablate & 16) mask = 0ull;
         tested += __popcll(mask);
         if (lane == 0) masks[g] = mask;
     }
@@ -271,7 +277,6 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
 
     // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
     // next chunk's landmarks prefetched into registers while the current one is processed.
-    if (a.dbg) st2 = clock64();
     for (int g = 0; g < a.n_groups && !skip_tier; ++g) {
         const int g0 = g * STRIDE;
         unsigned long long mask = masks[g];
@@ -319,9 +324,7 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
                     qcount -= 64;                                  // take the newest 64: the remainder stays in place
                     const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
                     // ---- 4. score
-                    const unsigned long long sc0 = a.dbg ? clock64() : 0ull;
-                    const bool opened = score_visible(a, table, lfac, bits, max_probe, ex, ey, ez, acc, overflow);
-                    if (a.dbg) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sc_clk += clock64() - sc0; sc_n += 1; }
+                    const bool opened = score_visible(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
                     const unsigned long long om = __ballot(opened);
                     if (!GLOBAL_TABLE && om != 0ull) {
                         int total = 0;
@@ -335,10 +338,12 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
             c1 = c2; x1 = x2; y1 = y2; z1 = z2;
         }
     }
-    if (a.dbg) st3 = clock64();
     if (skip_tier) qcount = 0;
     // flush the queue remainder
-    if (lane < qcount) score_visible(a, table, lfac, bits, max_probe, qx[lane], qy[lane], qz[lane], acc, overflow);
+    if (qcount > 0) {
+        const bool have = lane < qcount;
+        score_visible(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
+    }
     if (overflow) *v_overflow = 1;
 
     // ---- 5. reduce: wave shuffles, then across waves through LDS
@@ -373,12 +378,6 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
             a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
         } else if (failed) {
             atomicAdd(&a.counters[3], 1ull);
-        }
-        if (a.dbg) {
-            const int tier = GLOBAL_TABLE ? 2 : ((tier_bits == a.hash_bits2 && a.hash_bits2 > a.hash_bits) ? 1 : 0);
-            unsigned long long *d = a.dbg + 8 * (size_t)c;
-            d[tier] = wall_clock64() - dbg_t0;
-            if (tier == 0) { d[3] = (unsigned long long)wg_tested; d[4] = sc_n; d[5] = st3 - st2; d[6] = sc_clk; }
         }
     }
     if (!last_use) __syncthreads();                                // LDS is reused by the workgroup's next candidate

@@ -1,0 +1,93 @@
+// fs_gridops.hip — grid staging and the frontier-cell stencil.
+//
+// (1) Brick scatter: a sparse map arrives as a list of 8x8x8 bricks (the wire / host format of a hashed voxel
+//     map); MI355X has 288 GB of HBM, so the scorer keeps the DENSE grid resident (1024^3 = 1 GiB) and the ray
+//     walk needs no hash probe per cell.  fs_upload_grid_bricks fills the grid with the default cost and
+//     scatters the bricks.
+// (2) Frontier-cell predicate of FrontierSearch::isNewFrontierCell (DEP/src/FrontierSearch.cpp:218-249,
+//     DEP/include/.../FrontierSearch.hpp:129-142): a cell is a frontier cell iff it is unknown (255), none of its
+//     in-plane 4-neighbours is lethal (>= lethal_threshold and != 255) and at least one is free
+//     (< lethal_threshold).  Edge cells simply have fewer neighbours (nhood4, DEP/src/Helpers.cpp:185-220).
+//     The BFS clustering around it is graph traversal and stays on the host (out of scope).
+#include "fs_internal.h"
+
+namespace {
+
+__global__ void fs_brick_scatter_kernel(int64_t n_bricks, const int32_t *coords, const uint8_t *cells,
+                                        uint8_t *grid, int nx, int ny, int nz, int *bad)
+{
+    // one 64-thread wave per brick: lane = (z, y) row of 8 cells
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= n_bricks) return;
+    const int lane = threadIdx.x & 63;
+    const int bx = coords[3 * b], by = coords[3 * b + 1], bz = coords[3 * b + 2];
+    const int x0 = bx * 8, y = by * 8 + (lane & 7), z = bz * 8 + (lane >> 3);
+    if (bx < 0 || by < 0 || bz < 0 || x0 + 8 > nx || by * 8 + 8 > ny || bz * 8 + 8 > nz) {
+        if (lane == 0) atomicOr(bad, 1);
+        return;
+    }
+    const uint2 row = *reinterpret_cast<const uint2 *>(cells + b * 512 + lane * 8);
+    *reinterpret_cast<uint2 *>(grid + ((size_t)z * ny + y) * nx + x0) = row;
+}
+
+__global__ __launch_bounds__(256)
+void fs_frontier_cells_kernel(const uint8_t *grid, int nx, int ny, int nz, int lethal_threshold,
+                              uint8_t *mask, unsigned long long *count)
+{
+    // one thread per 16 consecutive x cells of one (y, z) row
+    const int groups_x = (nx + 15) >> 4;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)groups_x * ny * nz;
+    int found = 0;
+    if (t < total) {
+        const int gx = (int)(t % groups_x);
+        const long long row = t / groups_x;
+        const int y = (int)(row % ny);
+        const size_t base = (size_t)row * nx;
+        const int x0 = gx * 16;
+        const int lt = lethal_threshold;
+        for (int k = 0; k < 16; ++k) {
+            const int x = x0 + k;
+            if (x >= nx) break;
+            const uint8_t c = grid[base + x];
+            uint8_t out = 0;
+            if (c == 255) {
+                bool has_free = false, has_lethal = false;
+                auto look = [&](uint8_t v) {
+                    if ((int)v < lt) has_free = true;
+                    if ((int)v >= lt && v != 255) has_lethal = true;
+                };
+                if (x > 0) look(grid[base + x - 1]);
+                if (x < nx - 1) look(grid[base + x + 1]);
+                if (y > 0) look(grid[base + x - nx]);
+                if (y < ny - 1) look(grid[base + x + nx]);
+                out = (!has_lethal && has_free) ? 1 : 0;
+            }
+            if (mask) mask[base + x] = out;
+            found += out;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) found += __shfl_xor(found, d);
+    if ((threadIdx.x & 63) == 0 && found) atomicAdd(count, (unsigned long long)found);
+}
+
+}  // namespace
+
+hipError_t fs_launch_brick_scatter(int64_t n_bricks, const int32_t *d_coords, const uint8_t *d_cells, uint8_t *d_grid,
+                                   int nx, int ny, int nz, int *d_bad, hipStream_t s)
+{
+    if (n_bricks <= 0) return hipSuccess;
+    const int per_block = 4;
+    hipLaunchKernelGGL(fs_brick_scatter_kernel, dim3((unsigned)((n_bricks + per_block - 1) / per_block)), dim3(64 * per_block), 0, s,
+                       n_bricks, d_coords, d_cells, d_grid, nx, ny, nz, d_bad);
+    return hipGetLastError();
+}
+
+hipError_t fs_launch_frontier_cells(const uint8_t *d_grid, int nx, int ny, int nz, int lethal_threshold, uint8_t *d_mask,
+                                    unsigned long long *d_count, hipStream_t s)
+{
+    const long long total = (long long)((nx + 15) >> 4) * ny * nz;
+    hipLaunchKernelGGL(fs_frontier_cells_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       d_grid, nx, ny, nz, lethal_threshold, d_mask, d_count);
+    return hipGetLastError();
+}

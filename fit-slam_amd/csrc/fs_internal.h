@@ -54,6 +54,10 @@ struct FsSegArgs {
     int32_t *traced, *unknown, *all;
 };
 hipError_t fs_launch_segments(const FsSegArgs &a, hipStream_t s);
+hipError_t fs_launch_brick_scatter(int64_t n_bricks, const int32_t *d_coords, const uint8_t *d_cells, uint8_t *d_grid,
+                                   int nx, int ny, int nz, int *d_bad, hipStream_t s);
+hipError_t fs_launch_frontier_cells(const uint8_t *d_grid, int nx, int ny, int nz, int lethal_threshold, uint8_t *d_mask,
+                                    unsigned long long *d_count, hipStream_t s);
 
 // ---- FIM kernel arguments ---------------------------------------------------------------------
 struct FsFimArgs {
@@ -64,7 +68,6 @@ struct FsFimArgs {
     int32_t n_chunks;
     int32_t n_groups;          // passes of (waves x 64) chunks per workgroup; set by the launcher per kernel configuration
     int32_t cull;              // 0: every chunk is tested (brute force)
-    int32_t ablate;            // development only (option "fim.ablate"): bit mask of stages to skip, results become wrong
     // dense lookup table indexed by the integer voxel lattice
     const float *table;        // [tx][ty][tz], NaN = absent
     int32_t jx0, jy0, jz0;     // lattice index of table[0][0][0]
@@ -91,7 +94,6 @@ struct FsFimArgs {
     int32_t *n_visible, *n_voxels;
     double *sums;              // [n][18] reduced per-candidate sums (info, 15 FIM block sums, n_visible, n_voxels)
     uint32_t *overflow;        // [n] tier that must re-score the candidate (0 = done)
-    unsigned long long *dbg;   // development only: [n][8] workgroup duration per tier (100 MHz ticks) + phase stamps (shader clocks), or nullptr
     int32_t *flagged;          // [2][n] work lists: candidates tier 1 / tier 2 hand to the next tier
     uint32_t *tested;          // [n] landmark tests spent on the candidate (all tiers); zeroed by the finish kernel
     unsigned long long *counters;   // [8]: 0 landmarks tested, 1..3 per-call tier failures, 4..6 their running totals

@@ -105,7 +105,8 @@ int  fs_synchronize(fs_ctx *ctx);
 
 /* Per-kernel device time.  With timing enabled every kernel launch is bracketed by hipEvents on
  * the context's stream; fs_kernel_time returns and resets the accumulated (ms, launches) of
- * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM larger-table tiers, 3 utility/rank, 4 candidate sort. */
+ * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM larger-table tiers, 3 utility/rank, 4 candidate sort,
+ * 5 frontier-cell stencil. */
 int  fs_enable_kernel_timing(fs_ctx *ctx, int enable);
 int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
 
@@ -129,6 +130,20 @@ int fs_ray_fan_shape(const fs_ctx *ctx, int32_t *n_yaw, int32_t *n_elev, int32_t
  * costmap mutex.  Invalidates cached arrival limits. */
 int fs_upload_grid(fs_ctx *ctx, const uint8_t *cells, int32_t nx, int32_t ny, int32_t nz,
                    const double origin_xyz[3], double resolution);
+
+/* Same snapshot from a SPARSE map: n_bricks bricks of 8x8x8 cells (brick_xyz [n][3] in brick units, brick_cells
+ * [n][512] with index (z*8 + y)*8 + x), everything else default_value (255 = unknown).  This is the wire format of
+ * a hashed voxel map (BASELINE.json configs[4], 1024^3); in HBM the grid stays dense (1 GiB of 288 GB) so that the
+ * ray walk needs no hash probe per cell.  Dimensions must be multiples of 8. */
+int fs_upload_grid_bricks(fs_ctx *ctx, int32_t nx, int32_t ny, int32_t nz, const double origin_xyz[3], double resolution,
+                          uint8_t default_value, int64_t n_bricks, const int32_t *brick_xyz, const uint8_t *brick_cells);
+
+/* Frontier-cell predicate of FrontierSearch::isNewFrontierCell (DEP/src/FrontierSearch.cpp:218-249; isFree / isLethal /
+ * isUnknown: DEP/include/.../FrontierSearch.hpp:129-142; frontierSearch/lethal_threshold 160) evaluated for every cell
+ * of the staged grid, slice by slice: unknown cell, no lethal in-plane 4-neighbour, at least one free one.
+ * mask [nz][ny][nx] (1 = frontier cell) may be NULL; *count = number of frontier cells.  The BFS clustering of the
+ * reference (searchFrom / buildNewFrontier) consumes this mask on the host. */
+int fs_frontier_cells(fs_ctx *ctx, int32_t lethal_threshold, uint8_t *mask, int64_t *count);
 
 /* Replaces double FrontierCostCalculator::setMaxArrivalInformation() (DEP/include/.../CostCalculator.hpp:58,
  * DEP/src/CostCalculator.cpp:123-191): geometric maximum of the FOV window on an obstacle-free fan from

@@ -373,3 +373,24 @@ def u1_costs(arrival, achievable, path_length, path_heading, max_arrival_gt, bla
     rc = lib().fso_u1_costs(n, _p(ar), _p(ac), _p(bl), _p(pl), _p(ph), alpha, beta, max_vx, max_wz,
                             float(max_arrival_gt), _p(cost), _p(au), _p(du))
     return rc, dict(weighted_cost=cost, arrival_utility=au, distance_utility=du)
+
+
+def frontier_cell_mask(cells, lethal_threshold=160):
+    """FrontierSearch::isNewFrontierCell over a whole grid (DEP/src/FrontierSearch.cpp:218-249; isFree/isLethal/isUnknown
+    DEP/include/.../FrontierSearch.hpp:129-142; nhood4 DEP/src/Helpers.cpp:185-220): unknown cell, no lethal in-plane
+    4-neighbour, at least one free one.  numpy restatement (byte arithmetic), slice by slice."""
+    c = np.asarray(cells, dtype=np.uint8)
+    if c.ndim == 2:
+        c = c[None]
+    free = c.astype(np.int32) < lethal_threshold
+    lethal = (c.astype(np.int32) >= lethal_threshold) & (c != 255)
+    unknown = c == 255
+
+    def any_nb(m):
+        out = np.zeros_like(m)
+        out[:, :, 1:] |= m[:, :, :-1]
+        out[:, :, :-1] |= m[:, :, 1:]
+        out[:, 1:, :] |= m[:, :-1, :]
+        out[:, :-1, :] |= m[:, 1:, :]
+        return out
+    return (unknown & ~any_nb(lethal) & any_nb(free)).astype(np.uint8)

@@ -311,3 +311,38 @@ def test_trace_segments_matches_oracle(fs, oracle, scorer):
                 if r["ok"]:
                     assert (got["traced"][i], bool(got["hit"][i]), got["unknown"][i], got["all"][i]) == \
                         (r["traced"], r["hit"], r["unknown"], r["all"]), i
+
+
+def test_frontier_cell_stencil(fs, oracle, scorer):
+    """isNewFrontierCell for every cell (the producer side of the candidate list)."""
+    for w in (fs.synth.make_small_2d(51, n=200, n_cand=4), fs.synth.make_workload("C1", n_cand=4)):
+        scorer.upload_grid(w.cells, w.origin, w.resolution)
+        for thr in (160, 254, 1):
+            mask, count = scorer.frontier_cells(w.cells.shape, thr)
+            want = oracle.frontier_cell_mask(w.cells, thr)
+            np.testing.assert_array_equal(mask, want)
+            assert count == int(want.sum())
+    edge = np.full((1, 5, 37), 255, np.uint8); edge[0, 0, 0] = 0; edge[0, 4, 36] = 0; edge[0, 2, 17] = 200; edge[0, 2, 19] = 0
+    scorer.upload_grid(edge, (0, 0, 0), 0.05)
+    mask, count = scorer.frontier_cells(edge.shape, 160)
+    np.testing.assert_array_equal(mask, oracle.frontier_cell_mask(edge, 160))
+    assert mask[0, 2, 18] == 0 and mask[0, 1, 19] == 1 and mask[0, 0, 1] == 1     # lethal neighbour vetoes; corners work
+
+
+def test_brick_upload_equals_dense_upload(fs, scorer):
+    """A sparse brick list (hashed-voxel-map wire format) must stage the same grid as the dense upload."""
+    w = fs.synth.make_workload("C1", n_cand=120)
+    _setup_scorer(scorer, w)
+    dense = scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+    nz, ny, nx = w.cells.shape
+    b = w.cells.reshape(nz // 8, 8, ny // 8, 8, nx // 8, 8).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 512)
+    bz, by, bx = np.meshgrid(np.arange(nz // 8), np.arange(ny // 8), np.arange(nx // 8), indexing="ij")
+    xyz = np.stack([bx.ravel(), by.ravel(), bz.ravel()], axis=1)
+    keep = ~(b == 255).all(axis=1)                     # all-unknown bricks are simply absent
+    assert 0 < keep.sum() < keep.size
+    scorer.upload_grid_bricks(w.cells.shape, w.origin, w.resolution, xyz[keep], b[keep], default_value=255)
+    sparse = scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+    for k in ("ray_counts", "arrival", "argmax", "achievable", "status"):
+        np.testing.assert_array_equal(sparse[k], dense[k])
+    with pytest.raises(fs.FsError):
+        scorer.upload_grid_bricks(w.cells.shape, w.origin, w.resolution, [[nx // 8, 0, 0]], b[:1])
