@@ -833,7 +833,8 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
 {
     if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    if (m > 65535 * FS_CHUNK) return fail(c, FS_E_INVALID, "at most %d landmarks per context", 65535 * FS_CHUNK);
+    // the per-wave chunk masks of the 1024-thread tier must fit the CU's LDS next to its 128-KiB table
+    if (m > 2000000) return fail(c, FS_E_INVALID, "at most 2,000,000 landmarks per context");
     // Morton order (10 bits per axis inside the cloud's bounding box) so that 64 consecutive landmarks
     // are spatial neighbours; non-finite points sort last.
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};

@@ -30,6 +30,9 @@ CONFIGS = {
                elev=(-0.30, -0.10, 0.10, 0.30), depth_cells=40),
     "C4": dict(index=4, n=512, nz=512, n_cand=160_000, n_landmarks=100_000, n_yaw=64,
                elev=(-0.30, -0.10, 0.10, 0.30), depth_cells=40),
+    # configs[4]: 1024^3 map (sparse brick list on the wire, dense 1 GiB in HBM), 50 k candidates, 500 k landmarks
+    "C5": dict(index=5, n=1024, nz=1024, n_cand=50_000, n_landmarks=500_000, n_yaw=64,
+               elev=(-0.30, -0.10, 0.10, 0.30), depth_cells=40),
 }
 
 RESOLUTION = 0.05
