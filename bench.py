@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--workload", default="C3", help="C3 (headline) | C2 | C1 (smaller, for rehearsal)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time; 0 disables")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the measured configuration) | gloo (rehearsal of the N > 1 path on one GPU: ranks share the device, records are gathered through host memory)")
     return ap.parse_args()
 
 
@@ -100,11 +101,15 @@ def main():
         print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     fs = importlib.import_module("fit-slam_amd")
     from importlib import import_module
@@ -118,7 +123,7 @@ def main():
     cap = shard.shard_capacity(n_total, world)
 
     stream = torch.cuda.current_stream(dev)
-    sc = fs.FrontierScorer(device=local_rank, stream=stream.cuda_stream)
+    sc = fs.FrontierScorer(device=dev_index, stream=stream.cuda_stream)
     arrival_kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
                       robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
     sc.set_ray_params(**arrival_kw)
@@ -138,7 +143,10 @@ def main():
     def step():
         sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_rec.data_ptr())
         if world > 1:
-            return shard.gather_records(d_rec, n_total)
+            if args.backend == "nccl":
+                return shard.gather_records(d_rec, n_total)
+            torch.cuda.synchronize(dev)
+            return shard.gather_records(d_rec.cpu(), n_total)       # gloo rehearsal: through host memory
         return d_rec[:n_total]
 
     def fence():
@@ -165,7 +173,7 @@ def main():
     sc.enable_kernel_timing(False)
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -203,7 +211,7 @@ def main():
             "config": {"workload": f"{args.workload}: {cfg['n']}^3 uint8 grid, {per_rank} candidates/GPU "
                                    f"({n_total} total), {m} landmarks, {R * E} rays/candidate ({R} yaw x {E} elevation), "
                                    f"L={L} cells, chunk-culled visibility (M_tested measured), reference 71x100x100 lookup table",
-                       "candidates_per_gpu": per_rank, "sharding": f"contiguous blocks over {world} GPU(s), one all-gather of 32-B records"},
+                       "candidates_per_gpu": per_rank, "sharding": f"contiguous blocks over {world} GPU(s), one all-gather of 32-B records ({args.backend})"},
             "roofline": {"bound": "hbm", "kernel": "fs_fim_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_candidate": b_fim, "m_tested_per_candidate": m_tested,
