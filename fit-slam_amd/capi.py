@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_upload_grid_bricks", "fs_frontier_cells", "fs_max_arrival", "fs_set_arrival_limits",
     "fs_score_arrival", "fs_trace_segments",
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
-    "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim",
+    "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim", "fs_information_frontier_pair",
     "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_selftest_fp64",
 ]
 
@@ -96,6 +96,7 @@ def load_library(build: bool = True):
     L.fs_lookup_query.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.fs_set_fim_params.argtypes = [vp, C.POINTER(FimParamsC)]
     L.fs_score_fim.argtypes = [vp, i32] + [vp] * 7
+    L.fs_information_frontier_pair.argtypes = [vp, i32, vp, vp, vp]
     L.fs_score_candidates.argtypes = [vp, i32] + [vp] * 5
     L.fs_score_candidates_dev.argtypes = [vp, i32] + [vp] * 5
     L.fs_rank_candidates.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp]
@@ -277,6 +278,13 @@ class FrontierScorer:
         nvis = np.zeros(n, dtype=np.int32); nvox = np.zeros(n, dtype=np.int32)
         self._check(self._L.fs_score_fim(self._h, n, _p(ps), _p(info), _p(fim21), _p(trace), _p(logdet), _p(nvis), _p(nvox)))
         return dict(info_ref=info, fim21=fim21, trace=trace, logdet=logdet, n_visible=nvis, n_voxels=nvox)
+
+    def information_frontier_pair(self, est_pose7, triangles_xy):
+        ps = np.ascontiguousarray(est_pose7, dtype=np.float64).reshape(-1, 7)
+        tr = np.ascontiguousarray(triangles_xy, dtype=np.float64).reshape(-1, 6)
+        out = np.zeros(ps.shape[0], dtype=np.float32)
+        self._check(self._L.fs_information_frontier_pair(self._h, ps.shape[0], _p(ps), _p(tr), _p(out)))
+        return out
 
     # -- fused
     def score_candidates(self, goal_xyz, frontier_size=None, blacklisted=None, achievable_in=None) -> np.ndarray:

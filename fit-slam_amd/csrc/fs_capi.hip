@@ -1081,6 +1081,27 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
     return FS_OK;
 }
 
+int fs_information_frontier_pair(fs_ctx *c, int32_t n, const double *est_pose7, const double *triangle_xy, float *information)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (!c->have_lm) return fail(c, FS_E_STATE, "fs_upload_landmarks has not been called");
+    if (n < 0 || (n > 0 && (!est_pose7 || !triangle_xy || !information))) return fail(c, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    std::vector<float> Rt((size_t)n * 12);
+    for (int32_t i = 0; i < n; ++i) pose_to_rt(est_pose7 + 7 * (size_t)i, &Rt[12 * (size_t)i]);
+    DevBuf<double> d_tri;
+    FS_HIP(c, c->d_Rt.ensure(Rt.size())); FS_HIP(c, d_tri.ensure((size_t)n * 6)); FS_HIP(c, c->d_info.ensure(n));
+    FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, Rt.data(), Rt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(d_tri.p, triangle_xy, sizeof(double) * 6 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    // the landmark arrays are Morton-ordered and padded with far-away sentinels: those never fall inside a triangle
+    FS_HIP(c, fs_launch_frontier_pair(n, c->d_lx.p, c->d_ly.p, c->d_lz.p, c->n_chunks * FS_CHUNK, c->d_Rt.p, d_tri.p, c->d_info.p, c->stream));
+    FS_HIP(c, hipMemcpyAsync(information, c->d_info.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    d_tri.release();
+    return FS_OK;
+}
+
 // ------------------------------------------------------------------ fused scoring
 
 int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, const int32_t *d_frontier_size,

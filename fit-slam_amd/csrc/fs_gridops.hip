@@ -71,7 +71,53 @@ void fs_frontier_cells_kernel(const uint8_t *grid, int nx, int ny, int nz, int l
     if ((threadIdx.x & 63) == 0 && found) atomicAdd(count, (unsigned long long)found);
 }
 
+// computeInformationFrontierPair (FIP/src/.../FisherInformationHelpers.cpp:125-143) for a batch: one workgroup per
+// (estimation pose, FOV triangle); every landmark whose (x, y) lies strictly inside the triangle (onLeft of all
+// three edges, evaluated in fp64 like the reference's Point2D arithmetic) adds the local-Jacobian trace
+// 2 + 2/|p|^2 at p = R^T (w - t).  The reference never calls it at run time; kept for interface completeness.
+__global__ __launch_bounds__(256)
+void fs_frontier_pair_kernel(int n, const float *lx, const float *ly, const float *lz, int m, const float *Rt,
+                             const double *tri, float *out)
+{
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    if (c >= n) return;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rt[12 * (size_t)c + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = Rt[12 * (size_t)c + 9 + i];
+    const double ax = tri[6 * c], ay = tri[6 * c + 1], bx = tri[6 * c + 2], by = tri[6 * c + 3], cx = tri[6 * c + 4], cy = tri[6 * c + 5];
+    float sum = 0.0f;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const float x = lx[i], y = ly[i], z = lz[i];
+        const bool l1 = (ax - x) * (by - y) - (ay - y) * (bx - x) > 0;
+        const bool l2 = (bx - x) * (cy - y) - (by - y) * (cx - x) > 0;
+        const bool l3 = (cx - x) * (ay - y) - (cy - y) * (ax - x) > 0;
+        if (l1 && l2 && l3) {
+            const float dx = x - t[0], dy = y - t[1], dz = z - t[2];
+            const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
+            const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
+            const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
+            const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
+            sum += 2.0f + 2.0f / n2;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 }  // namespace
+
+hipError_t fs_launch_frontier_pair(int n, const float *lx, const float *ly, const float *lz, int m, const float *d_Rt,
+                                   const double *d_tri, float *d_out, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fs_frontier_pair_kernel, dim3(n), dim3(256), 0, s, n, lx, ly, lz, m, d_Rt, d_tri, d_out);
+    return hipGetLastError();
+}
 
 hipError_t fs_launch_brick_scatter(int64_t n_bricks, const int32_t *d_coords, const uint8_t *d_cells, uint8_t *d_grid,
                                    int nx, int ny, int nz, int *d_bad, hipStream_t s)

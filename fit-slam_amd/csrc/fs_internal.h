@@ -56,6 +56,8 @@ struct FsSegArgs {
 hipError_t fs_launch_segments(const FsSegArgs &a, hipStream_t s);
 hipError_t fs_launch_brick_scatter(int64_t n_bricks, const int32_t *d_coords, const uint8_t *d_cells, uint8_t *d_grid,
                                    int nx, int ny, int nz, int *d_bad, hipStream_t s);
+hipError_t fs_launch_frontier_pair(int n, const float *lx, const float *ly, const float *lz, int m, const float *d_Rt,
+                                   const double *d_tri, float *d_out, hipStream_t s);
 hipError_t fs_launch_frontier_cells(const uint8_t *d_grid, int nx, int ny, int nz, int lethal_threshold, uint8_t *d_mask,
                                     unsigned long long *d_count, hipStream_t s);
 

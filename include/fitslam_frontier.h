@@ -212,6 +212,14 @@ int fs_set_fim_params(fs_ctx *ctx, const fs_fim_params *p);
 int fs_score_fim(fs_ctx *ctx, int32_t n, const double *pose7, float *info_ref, float *fim21,
                  float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels);
 
+/* Replaces float computeInformationFrontierPair(std::vector<Point>& lndmrk_w, Pose& kf_pose_w, Pose& est_pose_w,
+ * std::vector<Point2D>& FOVFrontierPair) (FIP/src/.../FisherInformationHelpers.cpp:125-143; isInside / onLeft:
+ * FIP/include/.../FisherInformationHelpers.hpp:20-43) for a batch of (estimation pose, CCW triangle) pairs over the
+ * staged landmark cloud: sum of the local-Jacobian trace (computeInformationOfPointLocal, :106-112) of the landmarks
+ * whose (x, y) lies strictly inside the triangle.  triangle_xy [n][3][2].  (kf_pose_w only feeds an unused local in
+ * the reference; the function itself is not called at run time there.) */
+int fs_information_frontier_pair(fs_ctx *ctx, int32_t n, const double *est_pose7, const double *triangle_xy, float *information);
+
 /* ---------------------------------------------------------------- fused scoring */
 
 /* Replaces the scoring half of bool CostAssigner::getFrontierCosts(req, res)

@@ -176,6 +176,66 @@ float fso_information_of_point_local_world(const double pose7[7], const float p_
     return fso_information_of_point_local(p);
 }
 
+/* computeJacobianForPointGlobal + computeFIM + trace (FisherInformationHelpers.cpp:28-48,93-104). */
+float fso_information_of_point_global_world(const double pose7[7], const float p_w[3])
+{
+    float R[9], t[3], p[3];
+    fso_pose_to_rt(pose7, R, t);
+    fso_world_to_camera(R, t, p_w, p);                       /* :31 p_est = T^-1 p_w */
+    const float n = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    const float a = 1 / n, b = 1 / (n * n * n);
+    float A[9], L[9], Rm[18], D[18], J[18];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            A[3 * i + j] = a * (i == j ? 1.0f : 0.0f) - (b * p[i]) * p[j];   /* :35-36 */
+            L[3 * i + j] = R[3 * j + i];                                      /* :39 T^-1.rotation() = R^T */
+        }
+    float S[9];
+    skew_f(p_w, S);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Rm[6 * i + j] = (i == j ? 1.0f : 0.0f);                           /* :41 */
+            Rm[6 * i + 3 + j] = (float)(-1.0) * S[3 * i + j];                 /* :42 */
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j) {
+            float s = 0.0f;
+            for (int k = 0; k < 3; ++k) s += L[3 * i + k] * Rm[6 * k + j];    /* :43 */
+            D[6 * i + j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j) {
+            float s = 0.0f;
+            for (int k = 0; k < 3; ++k) s += A[3 * i + k] * D[6 * k + j];     /* :45 */
+            J[6 * i + j] = s;
+        }
+    float tr = 0.0f;
+    for (int j = 0; j < 6; ++j) {
+        float s = 0.0f;
+        for (int k = 0; k < 3; ++k) s += J[6 * k + j] * J[6 * k + j];
+        tr += s;
+    }
+    return tr;
+}
+
+/* onLeft(float x, float y, q, r) — FisherInformationHelpers.hpp:26-29 (Point2D fields are double) */
+static int on_left_f(float x, float y, double qx, double qy, double rx, double ry)
+{
+    return (qx - x) * (ry - y) - (qy - y) * (rx - x) > 0;
+}
+
+float fso_information_frontier_pair(const float *lm, int32_t m, const double est_pose7[7], const double tri[6])
+{
+    float pair_information = 0;                                               /* :129 */
+    for (int32_t i = 0; i < m; ++i) {
+        const float x = lm[3 * i], y = lm[3 * i + 1];
+        if (on_left_f(x, y, tri[0], tri[1], tri[2], tri[3]) && on_left_f(x, y, tri[2], tri[3], tri[4], tri[5]) &&
+            on_left_f(x, y, tri[4], tri[5], tri[0], tri[1]))                  /* :135 isInside */
+            pair_information += fso_information_of_point_local_world(est_pose7, lm + 3 * i);   /* :139 */
+    }
+    return pair_information;
+}
+
 /* ------------------------------------------------------------------ voxel key, crowding factor */
 
 /* getVoxelCoordinate — FisherInfoManager.hpp:108-123.  subSampleVoxelUntil_m = -1 makes the

@@ -159,6 +159,14 @@ int fso_pose_information(const fso_table *tab, const float *landmarks_xyz, int32
                          double *trace_f64, double *logdet_f64,
                          int32_t *n_visible, int32_t *n_voxels);
 
+/* computeInformationOfPointGlobal(p_c, p_w, T, Q = I) (FisherInformationHelpers.cpp:28-48,98-104):
+ * J = df_dp(p_est) * R^-1 * [ I | -[p_w]x ], returns trace(J^T J), float32. */
+float fso_information_of_point_global_world(const double pose7[7], const float p_w[3]);
+/* computeInformationFrontierPair (FisherInformationHelpers.cpp:125-143) with isInside/onLeft
+ * (FIP/include/.../FisherInformationHelpers.hpp:20-43): float32 running sum of the local trace at est_pose over
+ * the landmarks whose (x, y) lies strictly inside the triangle tri = {ax,ay,bx,by,cx,cy}. */
+float fso_information_frontier_pair(const float *landmarks_xyz, int32_t m, const double est_pose7[7], const double tri[6]);
+
 /* ------------------------------------------------------------------ U1 utility (next-row §8f.1) */
 /* assignCosts' utility loop + recomputeNormalizationFactors
  * (DEP/src/FrontierCostsManager.cpp:118,126-205; DEP/src/CostCalculator.cpp:512-520).

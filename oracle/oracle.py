@@ -99,6 +99,10 @@ def lib():
         L.fso_pose_information.restype = C.c_int
         L.fso_pose_information.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                            C.POINTER(_VisParams), C.c_int] + [C.c_void_p] * 7
+        L.fso_information_of_point_global_world.restype = C.c_float
+        L.fso_information_of_point_global_world.argtypes = [C.c_void_p, C.c_void_p]
+        L.fso_information_frontier_pair.restype = C.c_float
+        L.fso_information_frontier_pair.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.fso_u1_costs.restype = C.c_int
         L.fso_u1_costs.argtypes = [C.c_int32] + [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 3
         _lib = L
@@ -242,6 +246,19 @@ def information_of_point_local_world(pose7, p_w) -> float:
     a = np.ascontiguousarray(pose7, dtype=np.float64)
     b = np.ascontiguousarray(p_w, dtype=np.float32)
     return float(lib().fso_information_of_point_local_world(_p(a), _p(b)))
+
+
+def information_of_point_global_world(pose7, p_w) -> float:
+    a = np.ascontiguousarray(pose7, dtype=np.float64)
+    b = np.ascontiguousarray(p_w, dtype=np.float32)
+    return float(lib().fso_information_of_point_global_world(_p(a), _p(b)))
+
+
+def information_frontier_pair(landmarks_xyz, est_pose7, tri) -> float:
+    lm = np.ascontiguousarray(landmarks_xyz, dtype=np.float32).reshape(-1, 3)
+    a = np.ascontiguousarray(est_pose7, dtype=np.float64)
+    t = np.ascontiguousarray(tri, dtype=np.float64).reshape(6)
+    return float(lib().fso_information_frontier_pair(_p(lm), lm.shape[0], _p(a), _p(t)))
 
 
 def fim_point_local_f64(p) -> np.ndarray:

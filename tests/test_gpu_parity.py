@@ -346,3 +346,20 @@ def test_brick_upload_equals_dense_upload(fs, scorer):
         np.testing.assert_array_equal(sparse[k], dense[k])
     with pytest.raises(fs.FsError):
         scorer.upload_grid_bricks(w.cells.shape, w.origin, w.resolution, [[nx // 8, 0, 0]], b[:1])
+
+
+def test_information_frontier_pair(fs, oracle, scorer):
+    w = fs.synth.make_workload("C1", n_cand=30)
+    scorer.upload_landmarks(w.landmarks)
+    rng = np.random.default_rng(31)
+    poses = oracle.poses_from_yaw(w.goals, rng.uniform(-3, 3, size=30))
+    tris = []
+    for g, y in zip(w.goals, rng.uniform(-3, 3, size=30)):
+        a = g[:2]
+        b = a + 2.5 * np.array([np.cos(y - 0.5), np.sin(y - 0.5)])
+        c = a + 2.5 * np.array([np.cos(y + 0.5), np.sin(y + 0.5)])
+        tris.append([*a, *b, *c])
+    got = scorer.information_frontier_pair(poses, tris)
+    want = np.array([oracle.information_frontier_pair(w.landmarks, poses[i], tris[i]) for i in range(30)])
+    assert (want > 0).sum() > 10
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)

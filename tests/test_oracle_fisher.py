@@ -78,3 +78,31 @@ def test_threshold_decision(oracle, ref_table):
     few = oracle.pose_information(ref_table, lm[:200], pose)["info_ref"][0]
     many = oracle.pose_information(ref_table, lm, pose)["info_ref"][0]
     assert many > few > 0
+
+
+def test_global_jacobian_trace_and_frontier_pair(oracle):
+    """a14/a16 of SURVEY.md 8(a): computeInformationOfPointGlobal and computeInformationFrontierPair."""
+    rng = np.random.default_rng(12)
+    pose = [0.4, -1.1, 0.2, 0, 0, np.sin(0.35), np.cos(0.35)]
+    R, t = oracle.pose_to_rt(pose)
+    for _ in range(30):
+        w = rng.uniform(-6, 6, size=3).astype(np.float32)
+        p = oracle.world_to_camera(R, t, w).astype(np.float64)
+        n2 = p @ p
+        # closed form of trace(J^T J), J = A R^T [I | -[w]x]:  tr(A^T A (I + [w]x^T [w]x)) with A^T A = P/n^2 in the camera frame
+        P = (np.eye(3) - np.outer(p, p) / n2) / n2
+        Rm = R.astype(np.float64)
+        W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=np.float64)
+        M = Rm @ P @ Rm.T
+        want = np.trace(M) + np.trace(W.T @ M @ W)
+        got = oracle.information_of_point_global_world(pose, w)
+        assert abs(got - want) <= 2e-5 * want
+    lm = rng.uniform(-5, 5, size=(500, 3)).astype(np.float32)
+    tri = [0.0, 0.0, 4.0, -2.0, 4.0, 2.5]                      # counter-clockwise
+    got = oracle.information_frontier_pair(lm, pose, tri)
+    inside = [(tri[0] - x) * (tri[3] - y) - (tri[1] - y) * (tri[2] - x) > 0 and
+              (tri[2] - x) * (tri[5] - y) - (tri[3] - y) * (tri[4] - x) > 0 and
+              (tri[4] - x) * (tri[1] - y) - (tri[5] - y) * (tri[0] - x) > 0 for x, y in lm[:, :2].astype(np.float64)]
+    want = sum(oracle.information_of_point_local_world(pose, lm[i]) for i in np.nonzero(inside)[0])
+    assert sum(inside) > 10 and abs(got - want) <= 1e-5 * want
+    assert oracle.information_frontier_pair(lm, pose, [0.0, 0.0, 4.0, 2.5, 4.0, -2.0]) == 0.0     # clockwise: nothing is "left"
