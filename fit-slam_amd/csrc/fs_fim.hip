@@ -32,7 +32,7 @@
 
 #define FS_NACC 18       // info, 15 FIM block sums, n_visible, n_voxels
 #define FS_QCAP 128      // per-wave compaction queue (<= 63 left over + 64 new)
-#define FS_MAX_PROBE 96  // LDS tiers give up (-> next tier) after this many probes
+#define FS_MAX_PROBE 32  // LDS tiers give up (-> next tier) after this many bucket visits
 
 namespace {
 
@@ -47,26 +47,6 @@ struct Acc {
 __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
 {
     return (key * 2654435761u) >> (32 - bits);
-}
-
-// Generic find-or-insert from probe position h (slow path: collisions).  Returns the rank (1-based), 0 if no slot
-// was found within max_probe probes.
-__device__ __noinline__ uint32_t table_bump_slow(uint32_t *table, uint32_t mask, uint32_t tag, uint32_t h, uint32_t max_probe, bool &is_new)
-{
-    for (uint32_t probe = 1; probe < max_probe; ++probe) {
-        h = (h + 1u) & mask;
-        uint32_t cur = table[h];
-        if (cur == 0u) {
-            const uint32_t prev = atomicCAS(&table[h], 0u, tag | 1u);
-            if (prev == 0u) { is_new = true; return 1u; }
-            cur = prev;
-        }
-        if ((cur & ~FS_SLOT_CNT_MASK) == tag) {
-            if ((cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT) return FS_SLOT_CNT_SAT + 1u;
-            return (atomicAdd(&table[h], 1u) & FS_SLOT_CNT_MASK) + 1u;
-        }
-    }
-    return 0u;
 }
 
 // Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch).
@@ -96,14 +76,17 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
     const float info_t = a.table[key];
 
-    // ---- first probe of the voxel's hash slot (the reference's pointCount bookkeeping, :296-304)
-    const uint32_t mask = (1u << bits) - 1u;
-    const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
-    const uint32_t h = hash_key(key, bits);
-    // a table without holes (every generated table) lets the update start without waiting for the gathered value
+    // a table without holes (every generated table) lets the hash update start without waiting for the gathered value
     bool valid = in_table;
     if (!a.table_full) valid = valid && (info_t == info_t);
-    uint32_t cur = valid ? table[h] : 0xffffffffu;
+    // ---- the voxel's hash bucket (the reference's pointCount bookkeeping, :296-304).  The table is organised in
+    // buckets of four slots read with ONE 16-byte LDS load: at the load factors used (< 0.5) a bucket almost never
+    // fills up, so nearly every landmark resolves with one read plus one atomic instead of walking a probe chain.
+    const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
+    const uint32_t bmask = (1u << (bits - 2)) - 1u;
+    uint32_t hb = hash_key(key, bits - 2);
+    uint4 bk = make_uint4(0u, 0u, 0u, 0u);
+    if (valid) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
 
     // ---- unit-weight FIM block sums, F(p) = [[P/n^2, -S/n^2],[S/n^2, P]]; P's diagonal as a
     // sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector has no Jacobian.
@@ -118,20 +101,37 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         acc.s[0] += qx; acc.s[1] += qy; acc.s[2] += qz;
     }
 
-    const bool try_cas = valid && cur == 0u;
-    if (try_cas) cur = atomicCAS(&table[h], 0u, tag | 1u);           // returns 0 when this lane created the entry
-    const bool won = try_cas && cur == 0u;
-    const bool match = valid && !won && (cur & ~FS_SLOT_CNT_MASK) == tag;
-    const bool sat = match && (cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT;   // factor is 0.0f out there anyway
-    uint32_t old = 0u;
-    if (match && !sat) old = atomicAdd(&table[h], 1u);
-    uint32_t rank = won ? 1u : (match ? (sat ? FS_SLOT_CNT_SAT + 1u : (old & FS_SLOT_CNT_MASK) + 1u) : 0u);
-    bool is_new = won;
-    const bool unresolved = valid && !won && !match;                  // the slot holds another voxel: keep probing
-    if (unresolved) {
-        rank = table_bump_slow(table, mask, tag, h, max_probe, is_new);
-        if (rank == 0u) overflow = true;
+    uint32_t rank = 0u;
+    bool is_new = false;
+    bool done = !valid;
+    for (uint32_t probe = 0; probe < max_probe; ++probe) {
+        if (probe != 0u) {
+            if (__all(done)) break;                                       // second round trips are rare
+            if (!done) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
+        }
+        const uint32_t w0 = bk.x, w1 = bk.y, w2 = bk.z, w3 = bk.w;
+        const int jm = ((w0 & ~FS_SLOT_CNT_MASK) == tag) ? 0 : ((w1 & ~FS_SLOT_CNT_MASK) == tag) ? 1
+                     : ((w2 & ~FS_SLOT_CNT_MASK) == tag) ? 2 : ((w3 & ~FS_SLOT_CNT_MASK) == tag) ? 3 : -1;
+        const int je = (w0 == 0u) ? 0 : (w1 == 0u) ? 1 : (w2 == 0u) ? 2 : (w3 == 0u) ? 3 : -1;   // slots fill in order
+        const bool has_match = jm >= 0;
+        const bool can_insert = !has_match && je >= 0;
+        uint32_t *slot = table + (hb << 2) + (has_match ? jm : (je >= 0 ? je : 0));
+        uint32_t prev = 0xffffffffu;
+        if (!done && can_insert) prev = atomicCAS(slot, 0u, tag | 1u);    // 0: this lane created the entry
+        const bool won = !done && can_insert && prev == 0u;
+        const bool late = !done && can_insert && prev != 0u && (prev & ~FS_SLOT_CNT_MASK) == tag;   // my voxel just arrived there
+        const bool do_add = !done && (has_match || late);
+        const uint32_t cur = has_match ? (jm == 0 ? w0 : jm == 1 ? w1 : jm == 2 ? w2 : w3) : prev;
+        const bool sat = do_add && (cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT;                      // factor is 0.0f out there anyway
+        uint32_t old = 0u;
+        if (do_add && !sat) old = atomicAdd(slot, 1u);
+        if (won) { rank = 1u; is_new = true; }
+        if (do_add) rank = sat ? FS_SLOT_CNT_SAT + 1u : (old & FS_SLOT_CNT_MASK) + 1u;
+        const bool full = !done && !has_match && je < 0;                  // bucket holds four other voxels: next bucket
+        if (full) hb = (hb + 1u) & bmask;
+        done = done || won || do_add;                                     // a lost CAS against another voxel re-reads the bucket
     }
+    if (!done) { overflow = true; rank = 0u; }
     acc.nvox += is_new ? 1 : 0;                                       // occupied_voxel_count_++ (:304)
     // crowding factor exp(1 - k^0.8) from the LDS copy (entry 0 and everything beyond rank ~340 are 0.0f).
     // :318 — (float)(double information * float factor): the double product of two floats is exact, so one
@@ -172,7 +172,7 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
                                               uint32_t fail_code, bool last_use)
 {
     constexpr int WAVES = THREADS / 64;
-    const uint32_t max_probe = GLOBAL_TABLE ? (1u << bits) : FS_MAX_PROBE;
+    const uint32_t max_probe = GLOBAL_TABLE ? (1u << bits) : FS_MAX_PROBE;   // bucket visits incl. re-reads
     const int tier_bits = bits;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
