@@ -1122,6 +1122,8 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     ra.ray_counts = nullptr;
     ra.arrival = c->d_arrival.p; ra.argmax = c->d_argmax.p; ra.status = c->d_status.p;
     ra.yaw = c->d_yaw.p; ra.achievable = c->d_ach.p;
+    FS_HIP(c, c->d_Rt.ensure((size_t)n * 12));
+    ra.yawR = c->d_yawR.p; ra.pose12 = c->d_Rt.p;
     rc = maybe_sort(c, ra);
     if (rc) return rc;
     {
@@ -1130,8 +1132,8 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     }
     FsFimArgs fa{};
     fill_fim_args(c, fa);
-    fa.n = n; fa.Rt = nullptr;
-    fa.goal = d_goal_xyz; fa.argmax = c->d_argmax.p; fa.status = c->d_status.p; fa.yawR = c->d_yawR.p;
+    fa.n = n; fa.Rt = c->d_Rt.p;
+    fa.status = c->d_status.p;
     fa.fim21 = nullptr;
     rc = run_fim(c, fa);
     if (rc) return rc;

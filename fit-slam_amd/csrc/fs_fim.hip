@@ -181,17 +181,11 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
 
     // ---- pose
     float R[9], t[3];
-    if (a.Rt) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = a.Rt[12 * (size_t)c + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t[i] = a.Rt[12 * (size_t)c + 9 + i];
-    } else {
-        const int idx = a.argmax[c];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = a.yawR[9 * idx + i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t[i] = (float)a.goal[3 * (size_t)c + i];   // getTransformFromPose: float translation
+    {
+        const float4 *p4 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c);
+        const float4 r0 = p4[0], r1 = p4[1], r2 = p4[2];
+        R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+        R[8] = r2.x; t[0] = r2.y; t[1] = r2.z; t[2] = r2.w;
     }
 
     // px = ax*dx + ay*dy + az*dz: the camera's +x axis in the world frame
@@ -204,12 +198,10 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass.
     // All passes are issued before the table is cleared so that their latency overlaps the clear.
     int tested = 0;                                            // wave-uniform: chunks this wave will scan
-    for (int g = 0; g < a.n_groups; ++g) {
-        const int j = g * STRIDE + lane * WAVES + wave;
+    auto cull_one = [&](int j, const float4 s) -> bool {
         bool keep = j < a.n_chunks;
         if (keep && a.cull) {
-            const float4 s = spheres[j];                       // s.w carries a safety margin: the test is conservative
-            const float dx = s.x - t[0], dy = s.y - t[1], dz = s.z - t[2];
+            const float dx = s.x - t[0], dy = s.y - t[1], dz = s.z - t[2];   // s.w carries a safety margin: conservative
             const float d2 = dx * dx + dy * dy + dz * dz;
             const float reach = a.max_dist_f + s.w;
             keep = d2 <= reach * reach;
@@ -223,9 +215,25 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
                 keep = dot >= dist * cab - 1.0e-4f * dist - 1.0e-4f;
             }
         }
-        unsigned long long mask = __ballot(keep);
-        tested += __popcll(mask);
-        if (lane == 0) masks[g] = mask;
+        return keep;
+    };
+    for (int gb = 0; gb < a.n_groups; gb += 4) {
+        // four sphere loads in flight per lane (one latency for up to 2048 chunks per 512-thread workgroup)
+        float4 sp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = (gb + u) * STRIDE + lane * WAVES + wave;
+            sp[u] = (gb + u < a.n_groups && j < a.n_chunks) ? spheres[j] : make_float4(0.f, 0.f, 0.f, -1.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (gb + u < a.n_groups) {
+                const int j = (gb + u) * STRIDE + lane * WAVES + wave;
+                const unsigned long long mask = __ballot(cull_one(j, sp[u]));
+                tested += __popcll(mask);
+                if (lane == 0) masks[gb + u] = mask;
+            }
+        }
     }
 
     // chunks accepted by the whole workgroup: every wave publishes its count, one barrier, everyone sums

@@ -41,6 +41,8 @@ struct FsRayArgs {
     int32_t *arrival, *argmax, *status;
     double *yaw;
     uint8_t *achievable;
+    const float *yawR;         // [n_windows][9] rotation per argmax index (for pose12)
+    float *pose12;             // [n][12] R (row-major) + t of the pose (goal, best yaw), or nullptr
 };
 
 // ---- generic segment tracing (getTracedCells + a RayTracedCells visitor per segment)
@@ -84,13 +86,10 @@ struct FsFimArgs {
     float cos2;                // c*c, c = (float)cos(max_angle)
     int32_t cone_mode;         // 0 disabled, 1 c >= 0 (cone also culled per chunk), 2 c < 0, 3 c >= 0 but too wide to cull
     float max_dist_f, cos_a, sin_a;   // chunk culling (cone culled only in mode 1)
-    // poses: either explicit Rt[n][12] (R row-major 9 + t 3) or from the arrival outputs
+    // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;
-    const float *Rt;           // explicit poses or nullptr
-    const double *goal;        // [n][3]       (pose-from-arrival mode)
-    const int32_t *argmax;     // [n]
+    const float *Rt;
     const int32_t *status;     // [n] or nullptr: status != 0 -> zero FI
-    const float *yawR;         // [n_windows][9] rotation per argmax index
     // outputs (device)
     float *info_ref, *trace, *logdet, *fim21;   // fim21 may be nullptr
     int32_t *n_visible, *n_voxels;

@@ -225,6 +225,12 @@ void fs_raymarch_kernel(const FsRayArgs a)
         a.achievable[c] = ach;
         a.status[c] = FS_STATUS_OK;
     }
+    // pose (goal, best yaw) of the Fisher-information stage as one 48-byte record: rotation of
+    // orientationAroundZAxis(yaw) (table indexed by the argmax) and the float32 translation of getTransformFromPose
+    if (a.pose12 && lane < 12) {
+        const float v = lane < 9 ? a.yawR[9 * best_i + lane] : (float)a.goal[3 * (size_t)c + (lane - 9)];
+        a.pose12[12 * (size_t)c + lane] = v;
+    }
 }
 
 // One lane per segment: getTracedCells(sx, sy, wx, wy, visitor, max_length, costmap) for arbitrary end points
