@@ -25,12 +25,18 @@ EXPORTED_SYMBOLS = [
     "fs_score_arrival", "fs_trace_segments",
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim", "fs_information_frontier_pair",
+    "fs_upload_keyframes", "fs_information_for_pose",
     "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_selftest_fp64",
 ]
 
 RECORD_DTYPE = np.dtype([("arrival", "<i4"), ("argmax", "<i4"), ("yaw", "<f4"), ("info_ref", "<f4"),
                          ("trace", "<f4"), ("logdet", "<f4"), ("n_visible", "<i4"), ("flags", "<u4")])
 assert RECORD_DTYPE.itemsize == 32
+
+
+class KeyframeParamsC(C.Structure):
+    _fields_ = [("max_depth", C.c_double), ("hfov", C.c_double), ("max_depth_error", C.c_double),
+                ("q_diag", C.c_float), ("radius", C.c_double)]
 
 
 class RayParamsC(C.Structure):
@@ -97,6 +103,8 @@ def load_library(build: bool = True):
     L.fs_set_fim_params.argtypes = [vp, C.POINTER(FimParamsC)]
     L.fs_score_fim.argtypes = [vp, i32] + [vp] * 7
     L.fs_information_frontier_pair.argtypes = [vp, i32, vp, vp, vp]
+    L.fs_upload_keyframes.argtypes = [vp, i32, vp, vp, vp]
+    L.fs_information_for_pose.argtypes = [vp, i32, vp, C.POINTER(KeyframeParamsC), vp, vp, vp]
     L.fs_score_candidates.argtypes = [vp, i32] + [vp] * 5
     L.fs_score_candidates_dev.argtypes = [vp, i32] + [vp] * 5
     L.fs_rank_candidates.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp]
@@ -285,6 +293,25 @@ class FrontierScorer:
         out = np.zeros(ps.shape[0], dtype=np.float32)
         self._check(self._L.fs_information_frontier_pair(self._h, ps.shape[0], _p(ps), _p(tr), _p(out)))
         return out
+
+    # -- key-frame pose information (computeInformationForPose)
+    def upload_keyframes(self, kf_pose7, kf_offsets, points_xyz):
+        kf = np.ascontiguousarray(kf_pose7, dtype=np.float64).reshape(-1, 7)
+        off = np.ascontiguousarray(kf_offsets, dtype=np.int32)
+        pts = np.ascontiguousarray(points_xyz, dtype=np.float32).reshape(-1, 3)
+        if off.shape[0] != kf.shape[0] + 1 or (off.shape[0] and off[-1] != pts.shape[0]):
+            raise ValueError("kf_offsets must have n_keyframes + 1 entries ending at the number of points")
+        self._check(self._L.fs_upload_keyframes(self._h, kf.shape[0], _p(kf), _p(off), _p(pts)))
+
+    def information_for_pose(self, pose7, max_depth=2.0, hfov=1.089, max_depth_error=0.5, q_diag=0.01, radius=4.5):
+        ps = np.ascontiguousarray(pose7, dtype=np.float64).reshape(-1, 7)
+        n = ps.shape[0]
+        prm = KeyframeParamsC(float(max_depth), float(hfov), float(max_depth_error), float(np.float32(q_diag)), float(radius))
+        info = np.zeros(n, dtype=np.float32)
+        cells = np.zeros(n, dtype=np.int32)
+        pts = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_information_for_pose(self._h, n, _p(ps), C.byref(prm), _p(info), _p(cells), _p(pts)))
+        return dict(information=info, n_cells=cells, n_points=pts)
 
     # -- fused
     def score_candidates(self, goal_xyz, frontier_size=None, blacklisted=None, achievable_in=None) -> np.ndarray:

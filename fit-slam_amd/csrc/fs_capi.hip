@@ -76,6 +76,8 @@ struct fs_ctx {
     int32_t m = 0, n_chunks = 0;
     DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
     bool opt_cull = true;
+    int opt_bits1 = 14;            // development knobs (fs_set_option "fim.bits1", "fim.skip32")
+    int opt_skip32 = 15;
     DevBuf<unsigned long long> d_counters;
 
     // lookup table
@@ -90,6 +92,17 @@ struct fs_ctx {
 
     // fim parameters
     fs_fim_params fp{14.0, 1.0};
+
+    // key-frames (computeInformationForPose)
+    bool have_kf = false;
+    int32_t n_kf = 0;
+    int64_t n_kf_points = 0;
+    std::vector<double> kf_pose;          // host copy [n_kf][7]: the check points depend on the call's parameters
+    DevBuf<double> d_kf_check, d_kf_tri;
+    DevBuf<int32_t> d_kf_off, d_kf_flagged, d_kf_cells, d_kf_points;
+    DevBuf<float> d_kpx, d_kpy, d_kpz;
+    DevBuf<uint32_t> d_kf_gtable;
+    DevBuf<unsigned long long> d_kf_counters;
 
     // hash tables
     DevBuf<uint32_t> d_gtable;
@@ -397,10 +410,11 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     // tier 1: 2^14 LDS slots (64 KiB, two 512-thread workgroups per CU) or fewer for small clouds;
     // tier 2: 2^15 slots (128 KiB, one 1024-thread workgroup per CU); tier 3: HBM
     int bits = 10;
-    while (bits < 14 && (1 << bits) < 2 * c->m) ++bits;
+    while (bits < c->opt_bits1 && (1 << bits) < 2 * c->m) ++bits;
     a.hash_bits = bits;
     a.hash_bits2 = ((1 << bits) < 2 * c->m) ? 15 : bits;
     a.fail_code1 = (a.hash_bits2 > a.hash_bits) ? 1u : 2u;
+    a.skip32 = c->opt_skip32;
     a.gtable = c->d_gtable.p;
     a.ghash_bits = c->ghash_bits;
     a.counters = c->d_counters.p;
@@ -466,6 +480,9 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_dir.release(); c->d_yawR.release(); c->d_cells.release();
     c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
+    c->d_kf_check.release(); c->d_kf_tri.release(); c->d_kf_off.release(); c->d_kf_flagged.release(); c->d_kf_cells.release();
+    c->d_kf_points.release(); c->d_kpx.release(); c->d_kpy.release(); c->d_kpz.release(); c->d_kf_gtable.release();
+    c->d_kf_counters.release();
     c->d_goal.release(); c->d_yaw.release(); c->d_len.release(); c->d_head.release();
     c->d_cost.release(); c->d_au.release(); c->d_du.release(); c->d_sums.release();
     c->d_fsize.release(); c->d_arrival.release(); c->d_argmax.release(); c->d_status.release();
@@ -922,6 +939,8 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
+    if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);
 }
 
@@ -1099,6 +1118,120 @@ int fs_information_frontier_pair(fs_ctx *c, int32_t n, const double *est_pose7, 
     FS_HIP(c, hipMemcpyAsync(information, c->d_info.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
     d_tri.release();
+    return FS_OK;
+}
+
+// ------------------------------------------------------------------ key-frame pose information (row a24)
+
+namespace {
+
+// quatToEuler(...)[2] (util.hpp:77-88): tf2::Matrix3x3(tf2::Quaternion).getRPY, yaw component.  tf2 is third party;
+// setRotation / getEulerYPR as published for Humble (gimbal-lock branch returns yaw 0).
+double yaw_of_quaternion(const double q[4])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double s = 2.0 / (x * x + y * y + z * z + w * w);
+    const double ys = y * s, zs = z * s;
+    const double m00 = 1.0 - (y * ys + z * zs), m10 = x * ys + w * zs, m20 = x * zs - w * ys;
+    if (std::fabs(m20) >= 1.0) return 0.0;
+    const double cp = std::cos(-std::asin(m20));
+    return std::atan2(m10 / cp, m00 / cp);
+}
+
+// getVerticesOfFrustum2D (util.hpp:101-119)
+void frustum_triangle(const double pose7[7], double depth, double hfov, double t[6])
+{
+    const double yaw = yaw_of_quaternion(pose7 + 3);
+    t[0] = pose7[0]; t[1] = pose7[1];
+    t[2] = pose7[0] + depth * std::cos(yaw - hfov / 2); t[3] = pose7[1] + depth * std::sin(yaw - hfov / 2);
+    t[4] = pose7[0] + depth * std::cos(yaw + hfov / 2); t[5] = pose7[1] + depth * std::sin(yaw + hfov / 2);
+}
+
+}  // namespace
+
+int fs_upload_keyframes(fs_ctx *c, int32_t n_kf, const double *kf_pose7, const int32_t *kf_offsets, const float *points_xyz)
+{
+    if (!c || n_kf < 0 || (n_kf > 0 && (!kf_pose7 || !kf_offsets))) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    const int64_t total = n_kf > 0 ? kf_offsets[n_kf] : 0;
+    if (n_kf > 0 && kf_offsets[0] != 0) return fail(c, FS_E_INVALID, "kf_offsets[0] must be 0");
+    for (int32_t k = 0; k < n_kf; ++k)
+        if (kf_offsets[k + 1] < kf_offsets[k]) return fail(c, FS_E_INVALID, "kf_offsets must be non-decreasing");
+    if (total > 0 && !points_xyz) return fail(c, FS_E_INVALID, "null pointer");
+    std::vector<float> px((size_t)total), py((size_t)total), pz((size_t)total);
+    for (int64_t i = 0; i < total; ++i) { px[i] = points_xyz[3 * i]; py[i] = points_xyz[3 * i + 1]; pz[i] = points_xyz[3 * i + 2]; }
+    FS_HIP(c, c->d_kf_off.ensure((size_t)n_kf + 1));
+    FS_HIP(c, c->d_kpx.ensure((size_t)total)); FS_HIP(c, c->d_kpy.ensure((size_t)total)); FS_HIP(c, c->d_kpz.ensure((size_t)total));
+    const int32_t zero = 0;
+    FS_HIP(c, hipMemcpyAsync(c->d_kf_off.p, n_kf > 0 ? kf_offsets : &zero, sizeof(int32_t) * ((size_t)n_kf + 1), hipMemcpyHostToDevice, c->stream));
+    if (total > 0) {
+        FS_HIP(c, hipMemcpyAsync(c->d_kpx.p, px.data(), sizeof(float) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+        FS_HIP(c, hipMemcpyAsync(c->d_kpy.p, py.data(), sizeof(float) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+        FS_HIP(c, hipMemcpyAsync(c->d_kpz.p, pz.data(), sizeof(float) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+    }
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    c->kf_pose.assign(kf_pose7, kf_pose7 + 7 * (size_t)n_kf);
+    c->n_kf = n_kf; c->n_kf_points = total; c->have_kf = true;
+    return FS_OK;
+}
+
+int fs_information_for_pose(fs_ctx *c, int32_t n, const double *pose7, const fs_keyframe_params *prm,
+                            float *information, int32_t *n_cells, int32_t *n_points)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (!c->have_kf) return fail(c, FS_E_STATE, "fs_upload_keyframes has not been called");
+    if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
+    if (n < 0 || !prm || (n > 0 && (!pose7 || !information))) return fail(c, FS_E_INVALID, "null pointer");
+    if (!(prm->q_diag > 0.0f)) return fail(c, FS_E_INVALID, "q_diag must be positive");
+    if (n == 0) return FS_OK;
+    // host side: triangles (libm in double, like the reference) and poses
+    std::vector<double> tri((size_t)n * 12);
+    std::vector<float> Rt((size_t)n * 12);
+    for (int32_t i = 0; i < n; ++i) {
+        frustum_triangle(pose7 + 7 * (size_t)i, prm->max_depth, prm->hfov, &tri[12 * (size_t)i]);                          // :851
+        frustum_triangle(pose7 + 7 * (size_t)i, prm->max_depth + prm->max_depth_error, prm->hfov, &tri[12 * (size_t)i + 6]);   // :174
+        pose_to_rt(pose7 + 7 * (size_t)i, &Rt[12 * (size_t)i]);
+    }
+    // getVerticesToCheck (util.hpp:134-156) of every key-frame at depth + error
+    std::vector<double> chk((size_t)c->n_kf * 12);
+    for (int32_t k = 0; k < c->n_kf; ++k) {
+        double *o = &chk[12 * (size_t)k];
+        frustum_triangle(&c->kf_pose[7 * (size_t)k], prm->max_depth + prm->max_depth_error, prm->hfov, o);
+        o[6] = (o[0] + o[2]) / 2;  o[7] = (o[1] + o[3]) / 2;
+        o[8] = (o[2] + o[4]) / 2;  o[9] = (o[3] + o[5]) / 2;
+        o[10] = (o[4] + o[0]) / 2; o[11] = (o[5] + o[1]) / 2;
+    }
+    // HBM tables of the fallback pass: every point could open its own cell
+    int gbits = 10;
+    const uint64_t worst = std::min<uint64_t>((uint64_t)c->n_kf_points, (uint64_t)c->nx * (uint64_t)c->ny);
+    while (gbits < 30 && ((uint64_t)1 << gbits) < 2 * worst) ++gbits;
+    int pool = 64;
+    while (pool > 1 && ((size_t)pool * 3 << gbits) * sizeof(uint32_t) > ((size_t)1 << 30)) pool >>= 1;
+    FS_HIP(c, c->d_kf_gtable.ensure((size_t)pool * 3 << gbits));
+    FS_HIP(c, c->d_kf_tri.ensure(tri.size())); FS_HIP(c, c->d_Rt.ensure(Rt.size())); FS_HIP(c, c->d_kf_check.ensure(chk.size()));
+    FS_HIP(c, c->d_info.ensure(n)); FS_HIP(c, c->d_kf_cells.ensure(n)); FS_HIP(c, c->d_kf_points.ensure(n));
+    FS_HIP(c, c->d_kf_flagged.ensure(n)); FS_HIP(c, c->d_kf_counters.ensure(1));
+    FS_HIP(c, hipMemcpyAsync(c->d_kf_tri.p, tri.data(), tri.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, Rt.data(), Rt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (!chk.empty()) FS_HIP(c, hipMemcpyAsync(c->d_kf_check.p, chk.data(), chk.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemsetAsync(c->d_kf_counters.p, 0, sizeof(unsigned long long), c->stream));
+    FsKfArgs a{};
+    a.n = n; a.tri = c->d_kf_tri.p; a.Rt = c->d_Rt.p;
+    a.n_kf = c->n_kf; a.kf_check = c->d_kf_check.p; a.kf_offsets = c->d_kf_off.p;
+    a.px = c->d_kpx.p; a.py = c->d_kpy.p; a.pz = c->d_kpz.p;
+    a.radius = prm->radius;
+    const float q = prm->q_diag;
+    a.qinv = (q * q) * (1 / (q * (q * q)));                   // Eigen's 3x3 cofactor inverse of q*I (util.hpp:722)
+    a.nx = c->nx; a.ny = c->ny; a.ox = c->origin[0]; a.oy = c->origin[1]; a.res = c->res;
+    a.info = c->d_info.p; a.n_cells = c->d_kf_cells.p; a.n_points = c->d_kf_points.p;
+    a.flagged = c->d_kf_flagged.p; a.counters = c->d_kf_counters.p;
+    a.gtable = c->d_kf_gtable.p; a.gbits = gbits;
+    FS_HIP(c, fs_launch_kf_info(a, pool, c->stream));
+    FS_HIP(c, hipMemcpyAsync(information, c->d_info.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (n_cells) FS_HIP(c, hipMemcpyAsync(n_cells, c->d_kf_cells.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (n_points) FS_HIP(c, hipMemcpyAsync(n_points, c->d_kf_points.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
     return FS_OK;
 }
 

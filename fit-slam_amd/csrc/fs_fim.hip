@@ -252,7 +252,7 @@ __device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_
     // (more than 3/4 full: linear probing crawls) goes straight to the next tier; the running voxel count in the
     // main loop is the exact safety net.
     // (only where the next tier is another LDS tier: falling through to the HBM tier by prediction alone is too costly)
-    const bool skip_tier = !GLOBAL_TABLE && fail_code == 1u && ((long long)wg_tested * 64 * 15 > (long long)(3 << (tier_bits - 2)) * 32);
+    const bool skip_tier = !GLOBAL_TABLE && fail_code == 1u && ((long long)wg_tested * 64 * a.skip32 > (long long)(3 << (tier_bits - 2)) * 32);
     if (!GLOBAL_TABLE) {
         int need = 10;
         while (need < tier_bits && (1 << need) < wg_tested * 64) ++need;

@@ -63,6 +63,28 @@ hipError_t fs_launch_frontier_pair(int n, const float *lx, const float *ly, cons
 hipError_t fs_launch_frontier_cells(const uint8_t *d_grid, int nx, int ny, int nz, int lethal_threshold, uint8_t *d_mask,
                                     unsigned long long *d_count, hipStream_t s);
 
+// ---- key-frame pose information (computeInformationForPose)
+struct FsKfArgs {
+    int32_t n;                 // poses
+    const double *tri;         // [n][12]: FOV triangle at max_depth, then at max_depth + max_depth_error (x0,y0,x1,y1,x2,y2)
+    const float *Rt;           // [n][12]
+    int32_t n_kf;
+    const double *kf_check;    // [n_kf][12]: the key-frame frustum's three vertices and three edge midpoints (depth + error)
+    const int32_t *kf_offsets; // [n_kf + 1] into the point arrays
+    const float *px, *py, *pz; // key-frame world points, SoA
+    double radius;             // < 0: no radius filter
+    float qinv;                // Q^-1 diagonal
+    int32_t nx, ny;
+    double ox, oy, res;
+    float *info;
+    int32_t *n_cells, *n_points;
+    int32_t *flagged;          // [n] poses redone with the HBM table
+    unsigned long long *counters;   // [1]
+    uint32_t *gtable;          // [pool][3][1 << gbits]
+    int32_t gbits;
+};
+hipError_t fs_launch_kf_info(const FsKfArgs &a, int pool, hipStream_t s);
+
 // ---- FIM kernel arguments ---------------------------------------------------------------------
 struct FsFimArgs {
     // landmarks: Morton-ordered SoA, n_chunks chunks of 64 (the tail padded with far-away sentinels),
@@ -101,6 +123,7 @@ struct FsFimArgs {
     // hash tables
     int32_t hash_bits;         // tier 1 (LDS, 512-thread workgroups)
     int32_t hash_bits2;        // tier 2 (LDS, 1024-thread workgroups); <= hash_bits disables the tier
+    int32_t skip32;            // tier-1 hand-over prediction: distinct voxels <= skip32/32 of the landmarks scanned
     uint32_t fail_code1;       // what tier 1 flags on failure: 1 (tier 2 exists) or 2 (straight to tier 3)
     uint32_t *gtable;          // tier 3: HBM tables [pool][1 << ghash_bits]
     int32_t ghash_bits;

@@ -9,6 +9,7 @@
 //   frontier_exploration::FrontierCostCalculator    <- DEP/include/.../CostCalculator.hpp:46-136, DEP/src/CostCalculator.cpp:5-191,512-520
 //   frontier_exploration::FrontierCostsManager      <- DEP/src/FrontierCostsManager.cpp:47-223
 //   frontier_exploration::CostAssigner (+ Request/Response) <- DEP/include/.../CostAssigner.hpp:43-100, DEP/src/CostAssigner.cpp:29-167
+//   frontier_exploration_information_affine::computeInformationForPose <- DEP/include/.../deprecated/util.hpp:840-916 (batched)
 //   roadmap_explorer::FisherInformationManager      <- FIP/include/.../FisherInfoManager.hpp:72-145, FIP/src/.../FisherInfoManager.cpp:31-324
 // (DEP/ = dev_ws/src/DEPRECATED/frontier_exploration/frontier_exploration/, FIP/ = dev_ws/src/fit-slam2/fisher_information_plugins/)
 //
@@ -513,6 +514,60 @@ private:
     std::shared_ptr<FrontierCostsManager> frontierCostsManager_;
 };
 }  // namespace frontier_exploration
+
+// ---- key-frame pose information (dead code in the reference) ------------------------------
+namespace slam_msgs_lite
+{
+// the fields of slam_msgs::msg::MapData the function reads (map_data.graph.poses / poses_id, map_data.nodes[].id / word_pts)
+struct KeyFrame { int id = 0; std::vector<frontier_exploration::Point> word_pts; };
+struct MapGraph { std::vector<frontier_exploration::PoseStamped> poses; std::vector<int> poses_id; };
+struct MapData { MapGraph graph; std::vector<KeyFrame> nodes; };
+}  // namespace slam_msgs_lite
+
+namespace frontier_exploration_information_affine
+{
+// Stages a MapData snapshot: graph pose i is paired with the node of the same id (getNodeDataAndOptTransform,
+// deprecated/util.hpp:791-818); a pose without node data contributes no points.
+inline void setMapData(frontier_exploration::ScoringContext &ctx, const slam_msgs_lite::MapData &map_data)
+{
+    std::unordered_map<int, const slam_msgs_lite::KeyFrame *> by_id;
+    for (auto it = map_data.nodes.rbegin(); it != map_data.nodes.rend(); ++it) by_id[it->id] = &*it;   // first match wins
+    const size_t n = map_data.graph.poses.size();
+    std::vector<double> pose(7 * n);
+    std::vector<int32_t> off(n + 1, 0);
+    std::vector<float> pts;
+    for (size_t i = 0; i < n; ++i) {
+        const auto &p = map_data.graph.poses[i].pose;
+        double *o = &pose[7 * i];
+        o[0] = p.position.x; o[1] = p.position.y; o[2] = p.position.z;
+        o[3] = p.orientation.x; o[4] = p.orientation.y; o[5] = p.orientation.z; o[6] = p.orientation.w;
+        auto it = i < map_data.graph.poses_id.size() ? by_id.find(map_data.graph.poses_id[i]) : by_id.end();
+        if (it != by_id.end())
+            for (const auto &w : it->second->word_pts) { pts.push_back((float)w.x); pts.push_back((float)w.y); pts.push_back((float)w.z); }
+        off[i + 1] = (int32_t)(pts.size() / 3);
+    }
+    ctx.check(fs_upload_keyframes(ctx.get(), (int32_t)n, pose.data(), off.data(), pts.data()), "fs_upload_keyframes");
+}
+
+// computeInformationForPose (deprecated/util.hpp:840-916) for a batch of poses against the staged MapData and costmap;
+// `radius` folds in getNodesInRadius (:616-632; 4.5 m at the call site, CostCalculator.cpp:354).  Q = q_diag * I.
+inline std::vector<float> computeInformationForPoses(frontier_exploration::ScoringContext &ctx,
+                                                     const std::vector<frontier_exploration::Pose> &poses, double max_depth,
+                                                     double hfov, double max_depth_error, float q_diag, double radius = 4.5)
+{
+    const int32_t n = (int32_t)poses.size();
+    std::vector<double> p7(7 * (size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        double *o = &p7[7 * (size_t)i];
+        o[0] = poses[i].position.x; o[1] = poses[i].position.y; o[2] = poses[i].position.z;
+        o[3] = poses[i].orientation.x; o[4] = poses[i].orientation.y; o[5] = poses[i].orientation.z; o[6] = poses[i].orientation.w;
+    }
+    fs_keyframe_params prm{max_depth, hfov, max_depth_error, q_diag, radius};
+    std::vector<float> info(n);
+    ctx.check(fs_information_for_pose(ctx.get(), n, p7.data(), &prm, info.data(), nullptr, nullptr), "fs_information_for_pose");
+    return info;
+}
+}  // namespace frontier_exploration_information_affine
 
 namespace roadmap_explorer
 {

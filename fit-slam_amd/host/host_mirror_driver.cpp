@@ -84,6 +84,25 @@ int main(int argc, char **argv)
     printf("isPoseSafe(pose0) -> %d, information %.6f (batch %.6f)\n", (int)safe, single, info[0]);
     if (single != info[0] || safe != (single > 550.0f)) ++failures;
 
+    // key-frame pose information (computeInformationForPose): the first 20 frontier poses act as key-frames, landmark j
+    // is a word point of key-frame j % 20
+    std::vector<float> kf_info;
+    {
+        slam_msgs_lite::MapData map_data;
+        const int n_kf = n < 20 ? n : 20;
+        for (int k = 0; k < n_kf; ++k) {
+            PoseStamped ps; ps.pose = poses[k];
+            map_data.graph.poses.push_back(ps);
+            map_data.graph.poses_id.push_back(100 + k);
+            slam_msgs_lite::KeyFrame kf; kf.id = 100 + k;
+            for (int32_t j = k; j < m; j += n_kf) { Point w; w.x = lm[3 * j]; w.y = lm[3 * j + 1]; w.z = lm[3 * j + 2]; kf.word_pts.push_back(w); }
+            map_data.nodes.push_back(kf);
+        }
+        frontier_exploration_information_affine::setMapData(*ctx, map_data);
+        kf_info = frontier_exploration_information_affine::computeInformationForPoses(*ctx, poses, 2.0, 1.089, 0.5, 0.01f, 4.5);
+        printf("computeInformationForPoses: pose0 %.4f\n", kf_info[0]);
+    }
+
     // error behaviour of the reference interface
     failures += expect_throw("Frontier getter on unset field", [] { Frontier fr; (void)fr.getArrivalInformation(); });
     failures += expect_throw("duplicate frontiers", [&] {
@@ -104,10 +123,10 @@ int main(int argc, char **argv)
     if (!o) { perror("result"); return 2; }
     for (int32_t i = 0; i < n; ++i) {
         const auto &fr = res_->frontier_list[i];
-        const double row[8] = {res_->frontier_arrival_information[i], fr->getGoalYaw(), (double)fr->isAchievable(),
+        const double row[9] = {res_->frontier_arrival_information[i], fr->getGoalYaw(), (double)fr->isAchievable(),
                                res_->frontier_costs[i], fr->getCost("arrival_gain_utility"), fr->getCost("distance_utility"),
-                               res_->frontier_distances[i], (double)info[i]};
-        fwrite(row, sizeof(double), 8, o);
+                               res_->frontier_distances[i], (double)info[i], (double)kf_info[i]};
+        fwrite(row, sizeof(double), 9, o);
     }
     fclose(o);
     printf("failures: %d\n", failures);

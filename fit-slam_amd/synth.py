@@ -221,3 +221,28 @@ def make_small_2d(seed: int, n: int = 96, n_cand: int = 64, n_landmarks: int = 6
                     blacklisted=(rng.random(n_cand) < 0.05).astype(np.uint8),
                     landmarks=lm, n_yaw=0, elev=(0.0,), max_camera_depth=2.0, delta_theta=0.10,
                     polygon=(origin[0] + 0.2, origin[1] + 0.2, origin[0] + n * res - 0.2, origin[1] + n * res - 0.2))
+
+
+def make_keyframes(w: Workload, n_kf: int, seed: int, points_per_kf: int = 300, reach: float = 3.0):
+    """slam_msgs MapData stand-in for computeInformationForPose: key-frame poses (yaw-only, at candidate goals) and, per
+    key-frame, the landmarks within `reach` metres in the plane (shared map points appear in several key-frames).
+    Returns (kf_pose7 [n_kf][7], kf_offsets [n_kf + 1], points_xyz [total][3])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    idx = rng.choice(w.goals.shape[0], size=n_kf, replace=w.goals.shape[0] < n_kf)
+    yaw = rng.uniform(-np.pi, np.pi, size=n_kf)
+    pose = np.zeros((n_kf, 7), dtype=np.float64)
+    pose[:, :2] = w.goals[idx, :2]
+    pose[:, 5] = np.sin(yaw / 2)
+    pose[:, 6] = np.cos(yaw / 2)
+    offsets = [0]
+    chunks = []
+    lm = w.landmarks
+    for k in range(n_kf):
+        d2 = (lm[:, 0] - pose[k, 0]) ** 2 + (lm[:, 1] - pose[k, 1]) ** 2
+        near = np.nonzero(d2 <= reach * reach)[0]
+        if near.size > points_per_kf:
+            near = np.sort(rng.choice(near, size=points_per_kf, replace=False))
+        chunks.append(lm[near])
+        offsets.append(offsets[-1] + near.size)
+    pts = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 3), dtype=np.float32)
+    return pose, np.asarray(offsets, dtype=np.int32), np.ascontiguousarray(pts, dtype=np.float32)

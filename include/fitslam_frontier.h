@@ -220,6 +220,29 @@ int fs_score_fim(fs_ctx *ctx, int32_t n, const double *pose7, float *info_ref, f
  * the reference; the function itself is not called at run time there.) */
 int fs_information_frontier_pair(fs_ctx *ctx, int32_t n, const double *est_pose7, const double *triangle_xy, float *information);
 
+/* Key-frame pose information.  Replaces, for a batch of poses,
+ *   std::pair<float, std::vector<Eigen::Vector3f>> frontier_exploration_information_affine::computeInformationForPose(
+ *       Pose& pose, std::vector<Pose>& neighbouring_poses, std::vector<int> neighbouring_ids, slam_msgs::msg::MapData&,
+ *       double max_depth, double hfov, double max_depth_error, Eigen::Matrix3f Q, bool pcl_return, Logger, Costmap2D*, bool)
+ * (DEP/include/frontier_exploration/deprecated/util.hpp:840-916; dead code in the reference — its call site is the commented
+ * block DEP/src/CostCalculator.cpp:326-365) together with getNodesInRadius (util.hpp:616-632), frustumOverlap (:172-185),
+ * getVerticesOfFrustum2D (:101-119), isPointInsideTriangle (:49-66) and the affine computeInformationOfPoint (:687-759).
+ * fs_upload_keyframes stages slam_msgs MapData: key-frame poses (graph.poses) and their world points (nodes[].word_pts)
+ * as a CSR list.  The costmap geometry (x/y origin, resolution, size) is the one of fs_upload_grid. */
+typedef struct fs_keyframe_params {
+    double max_depth;          /* 2.0   (CostCalculator.cpp:358) */
+    double hfov;               /* 1.089 */
+    double max_depth_error;    /* 0.5 */
+    float  q_diag;             /* Q = q_diag * I, 0.01f (CostCalculator.cpp:356) */
+    double radius;             /* getNodesInRadius radius, 4.5; < 0: every key-frame is a neighbour */
+} fs_keyframe_params;
+int fs_upload_keyframes(fs_ctx *ctx, int32_t n_keyframes, const double *kf_pose7 /* [n][7] xyz + quat xyzw */,
+                        const int32_t *kf_offsets /* [n + 1] */, const float *points_xyz /* [kf_offsets[n]][3] */);
+/* information [n]: the pose information (.first of the pair); n_cells [n]: information_map.size(); n_points [n]: points that
+ * were added (inside the FOV triangle and on the map); the last two may be NULL.  The point list of pcl_return is not produced. */
+int fs_information_for_pose(fs_ctx *ctx, int32_t n, const double *pose7, const fs_keyframe_params *params,
+                            float *information, int32_t *n_cells, int32_t *n_points);
+
 /* ---------------------------------------------------------------- fused scoring */
 
 /* Replaces the scoring half of bool CostAssigner::getFrontierCosts(req, res)

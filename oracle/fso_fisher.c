@@ -581,3 +581,195 @@ int fso_pose_information(const fso_table *tab, const float *landmarks_xyz, int32
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ key-frame pose information (row a24) */
+
+/* quatToEuler (util.hpp:77-88): tf2::Quaternion(x,y,z,w) -> tf2::Matrix3x3 -> getRPY, yaw only.
+ * tf2 is third party (not under /root/reference): setRotation and getEulerYPR restated from upstream Humble. */
+double fso_quat_to_yaw(const double q[4])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double d = x * x + y * y + z * z + w * w;
+    const double s = 2.0 / d;
+    const double xs = x * s, ys = y * s, zs = z * s;
+    const double wy = w * ys, wz = w * zs;
+    const double xx = x * xs, xy = x * ys, xz = x * zs;
+    const double yy = y * ys, zz = z * zs;
+    const double m00 = 1.0 - (yy + zz), m10 = xy + wz, m20 = xz - wy;
+    (void)xx;
+    if (fabs(m20) >= 1.0) return 0.0;                                 /* gimbal lock branch: yaw = 0 */
+    const double pitch = -asin(m20);
+    return atan2(m10 / cos(pitch), m00 / cos(pitch));
+}
+
+/* getVerticesOfFrustum2D (util.hpp:101-119) */
+void fso_frustum_vertices_2d(const double pose7[7], double max_depth, double hfov, double tri[6])
+{
+    const double yaw = fso_quat_to_yaw(pose7 + 3);
+    tri[0] = pose7[0];
+    tri[1] = pose7[1];
+    tri[2] = pose7[0] + max_depth * cos(yaw - hfov / 2);
+    tri[3] = pose7[1] + max_depth * sin(yaw - hfov / 2);
+    tri[4] = pose7[0] + max_depth * cos(yaw + hfov / 2);
+    tri[5] = pose7[1] + max_depth * sin(yaw + hfov / 2);
+}
+
+/* isPointInsideTriangle (util.hpp:49-66): barycentric, edges inclusive; a degenerate triangle gives inf/NaN -> false */
+int fso_point_in_triangle(double px, double py, const double t[6])
+{
+    const double v0x = t[4] - t[0], v0y = t[5] - t[1];
+    const double v1x = t[2] - t[0], v1y = t[3] - t[1];
+    const double v2x = px - t[0], v2y = py - t[1];
+    const double dot00 = v0x * v0x + v0y * v0y;
+    const double dot01 = v0x * v1x + v0y * v1y;
+    const double dot02 = v0x * v2x + v0y * v2y;
+    const double dot11 = v1x * v1x + v1y * v1y;
+    const double dot12 = v1x * v2x + v1y * v2y;
+    const double inv_denom = 1.0 / (dot00 * dot11 - dot01 * dot01);
+    const double u = (dot11 * dot02 - dot01 * dot12) * inv_denom;
+    const double v = (dot00 * dot12 - dot01 * dot02) * inv_denom;
+    return (u >= 0.0) && (v >= 0.0) && (u + v <= 1.0);
+}
+
+/* getVerticesToCheck (util.hpp:134-156): the three vertices and the three edge midpoints */
+static void vertices_to_check(const double pose7[7], double depth, double hfov, double out[12])
+{
+    double t[6];
+    fso_frustum_vertices_2d(pose7, depth, hfov, t);
+    memcpy(out, t, sizeof t);
+    out[6] = (t[0] + t[2]) / 2;  out[7] = (t[1] + t[3]) / 2;
+    out[8] = (t[2] + t[4]) / 2;  out[9] = (t[3] + t[5]) / 2;
+    out[10] = (t[4] + t[0]) / 2; out[11] = (t[5] + t[1]) / 2;
+}
+
+/* frustumOverlap (util.hpp:172-185) */
+int fso_frustum_overlap(const double cur[7], const double chk[7], double max_depth, double hfov, double err)
+{
+    double t[6], c[12];
+    fso_frustum_vertices_2d(cur, max_depth + err, hfov, t);
+    vertices_to_check(chk, max_depth + err, hfov, c);
+    for (int i = 0; i < 6; ++i)
+        if (fso_point_in_triangle(c[2 * i], c[2 * i + 1], t)) return 1;
+    return 0;
+}
+
+/* affine computeJacobianForPoint + computeFIM + trace (util.hpp:687-759).  Same Jacobian as
+ * computeJacobianForPointGlobal; Q^-1 through Eigen's 3x3 cofactor inverse of q*I: (q*q) * (1 / (q*(q*q))). */
+float fso_information_of_point_affine(const double pose7[7], const float p_w[3], float q)
+{
+    float R[9], t[3], p[3];
+    fso_pose_to_rt(pose7, R, t);
+    fso_world_to_camera(R, t, p_w, p);                       /* :690 */
+    const float n = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    const float a = 1 / n, b = 1 / (n * n * n);
+    float A[9], L[9], Rm[18], D[18], J[18], S[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            A[3 * i + j] = a * (i == j ? 1.0f : 0.0f) - (b * p[i]) * p[j];   /* :694-695 */
+            L[3 * i + j] = R[3 * j + i];                                      /* :698 */
+        }
+    skew_f(p_w, S);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            Rm[6 * i + j] = (i == j ? 1.0f : 0.0f);
+            Rm[6 * i + 3 + j] = (float)(-1.0) * S[3 * i + j];                 /* :701 */
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j) {
+            float s = 0.0f;
+            for (int k = 0; k < 3; ++k) s += L[3 * i + k] * Rm[6 * k + j];
+            D[6 * i + j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j) {
+            float s = 0.0f;
+            for (int k = 0; k < 3; ++k) s += A[3 * i + k] * D[6 * k + j];
+            J[6 * i + j] = s;
+        }
+    const float qinv = (q * q) * (1 / (q * (q * q)));                         /* :722 Q.inverse() */
+    float tr = 0.0f;
+    for (int j = 0; j < 6; ++j) {
+        float s = 0.0f;
+        for (int k = 0; k < 3; ++k) s += (J[6 * k + j] * qinv) * J[6 * k + j];
+        tr += s;
+    }
+    return tr;
+}
+
+/* closed form of the same value in float64: [2 + 2|w|^2 - |w x v|^2] / (n^2 q), v = (w - t)/n */
+static double info_point_affine_f64(const double pose7[7], const float p_w[3], float q)
+{
+    const double w[3] = {p_w[0], p_w[1], p_w[2]};
+    const double d[3] = {w[0] - (double)(float)pose7[0], w[1] - (double)(float)pose7[1], w[2] - (double)(float)pose7[2]};
+    const double n2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const double n = sqrt(n2);
+    const double v[3] = {d[0] / n, d[1] / n, d[2] / n};
+    const double c[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+    const double w2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    return (2.0 + 2.0 * w2 - (c[0] * c[0] + c[1] * c[1] + c[2] * c[2])) / (n2 * (double)q);
+}
+
+int fso_information_for_pose(const fso_grid *g, int32_t n, const double *pose7, int32_t n_kf, const double *kf_pose7,
+                             const int32_t *kf_offsets, const float *pts, const fso_kf_params *prm, int n_threads,
+                             float *info_ref, double *info_f64, int32_t *n_cells, int32_t *n_points)
+{
+    if (!g || !pose7 || !prm || n < 0 || n_kf < 0) return -1;
+    const size_t ncell = (size_t)g->nx * (size_t)g->ny;
+    int bad = 0;
+#pragma omp parallel num_threads(n_threads > 0 ? n_threads : 1)
+    {
+        /* information_map: value and point count per costmap index, plus the list of touched indices */
+        float *val = (float *)malloc(ncell * sizeof(float));
+        double *val64 = (double *)malloc(ncell * sizeof(double));
+        int32_t *cnt = (int32_t *)calloc(ncell, sizeof(int32_t));
+        uint32_t *touched = (uint32_t *)malloc(ncell * sizeof(uint32_t));
+        if (!val || !val64 || !cnt || !touched) {
+#pragma omp atomic write
+            bad = 1;
+        } else {
+#pragma omp for schedule(dynamic, 4)
+            for (int32_t c = 0; c < n; ++c) {
+                const double *pose = pose7 + 7 * (size_t)c;
+                double tri[6];
+                fso_frustum_vertices_2d(pose, prm->max_depth, prm->hfov, tri);                    /* :851 */
+                float pose_information = 0;                                                       /* :848 */
+                size_t nt = 0;
+                int32_t npts = 0;
+                for (int32_t k = 0; k < n_kf; ++k) {
+                    const double *kp = kf_pose7 + 7 * (size_t)k;
+                    if (prm->radius >= 0.0) {                                                     /* getNodesInRadius :616-632 */
+                        const double dx = kp[0] - pose[0], dy = kp[1] - pose[1];
+                        if (!(sqrt(dx * dx + dy * dy) <= prm->radius)) continue;
+                    }
+                    if (!fso_frustum_overlap(pose, kp, prm->max_depth, prm->hfov, prm->max_depth_error)) continue;   /* :855 */
+                    for (int32_t j = kf_offsets[k]; j < kf_offsets[k + 1]; ++j) {                 /* :860 word_pts */
+                        const float *w = pts + 3 * (size_t)j;
+                        if (!fso_point_in_triangle((double)w[0], (double)w[1], tri)) continue;    /* :863 */
+                        uint32_t mx, my, mz;
+                        if (!fso_world_to_map(g, (double)w[0], (double)w[1], g->origin_z, &mx, &my, &mz)) continue;   /* :866 */
+                        const uint32_t index = my * (uint32_t)g->nx + mx;                         /* getIndex */
+                        ++npts;
+                        if (cnt[index] == 0) {                                                    /* :879 */
+                            val[index] = fso_information_of_point_affine(pose, w, prm->q_diag);
+                            val64[index] = info_point_affine_f64(pose, w, prm->q_diag);
+                            touched[nt++] = index;
+                        }
+                        ++cnt[index];
+                        pose_information += val[index];                                           /* :873,880 */
+                    }
+                }
+                double s64 = 0.0;
+                for (size_t i = 0; i < nt; ++i) {
+                    s64 += (double)cnt[touched[i]] * val64[touched[i]];
+                    cnt[touched[i]] = 0;
+                }
+                if (info_ref) info_ref[c] = pose_information;
+                if (info_f64) info_f64[c] = s64;
+                if (n_cells) n_cells[c] = (int32_t)nt;
+                if (n_points) n_points[c] = npts;
+            }
+        }
+        free(val); free(val64); free(cnt); free(touched);
+    }
+    return bad ? -3 : 0;
+}

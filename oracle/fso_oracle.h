@@ -176,6 +176,33 @@ int fso_u1_costs(int32_t n, const double *arrival, const uint8_t *achievable, co
                  double alpha, double beta, double max_vx, double max_wz, double max_arrival_gt,
                  double *weighted_cost, double *arrival_utility, double *distance_utility);
 
+/* ------------------------------------------------------------------ key-frame pose information (§8a row a24) */
+/* computeInformationForPose (DEP/include/.../deprecated/util.hpp:840-916; dead code in the reference, call site in the
+ * commented block DEP/src/CostCalculator.cpp:326-365 with max_depth 2.0, hfov 1.089, max_depth_error 0.5, Q = 0.01 I,
+ * neighbours within 4.5 m).  Helpers restated alongside: isPointInsideTriangle (:49-66), quatToEuler (:77-88; tf2
+ * Matrix3x3::getRPY, third party: parity unpinned there), getVerticesOfFrustum2D (:101-119), getVerticesToCheck (:134-156),
+ * frustumOverlap (:172-185), getNodesInRadius (:616-632), the float32 affine Jacobian/FIM/trace (:687-759). */
+typedef struct {
+    double max_depth;        /* 2.0 */
+    double hfov;             /* 1.089 */
+    double max_depth_error;  /* 0.5 */
+    float q_diag;            /* Q = q_diag * I (0.01f) */
+    double radius;           /* getNodesInRadius (4.5); < 0: every key-frame is a neighbour */
+} fso_kf_params;
+double fso_quat_to_yaw(const double q_xyzw[4]);                       /* quatToEuler(...)[2] */
+void fso_frustum_vertices_2d(const double pose7[7], double max_depth, double hfov, double tri[6]);
+int fso_point_in_triangle(double px, double py, const double tri[6]);
+int fso_frustum_overlap(const double cur_pose7[7], const double check_pose7[7], double max_depth, double hfov, double err);
+/* computeInformationOfPoint(p_c, p_w, T_w_c_est, Q) of the affine namespace, Q = q_diag * I, float32 */
+float fso_information_of_point_affine(const double pose7[7], const float p_w[3], float q_diag);
+/* For each of n poses: key-frames k (poses kf_pose7[n_kf][7], points points_xyz[kf_offsets[k] .. kf_offsets[k+1]))
+ * in list order; per costmap cell the first point's value is computed once and added once per point in the cell.
+ * info_ref: the reference's sequential float32 sum; info_f64: sum_cell count * value (float64 arithmetic, closed form);
+ * n_cells: information_map.size(); n_points: points that passed triangle + worldToMap.  Uses the grid's x/y geometry only. */
+int fso_information_for_pose(const fso_grid *g, int32_t n, const double *pose7, int32_t n_kf, const double *kf_pose7,
+                             const int32_t *kf_offsets, const float *points_xyz, const fso_kf_params *prm, int n_threads,
+                             float *info_ref, double *info_f64, int32_t *n_cells, int32_t *n_points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,11 @@ class _VisParams(C.Structure):
     _fields_ = [("max_dist", C.c_double), ("max_angle", C.c_double)]
 
 
+class _KfParams(C.Structure):
+    _fields_ = [("max_depth", C.c_double), ("hfov", C.c_double), ("max_depth_error", C.c_double),
+                ("q_diag", C.c_float), ("radius", C.c_double)]
+
+
 _lib = None
 
 
@@ -103,6 +108,18 @@ def lib():
         L.fso_information_of_point_global_world.argtypes = [C.c_void_p, C.c_void_p]
         L.fso_information_frontier_pair.restype = C.c_float
         L.fso_information_frontier_pair.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.fso_quat_to_yaw.restype = C.c_double
+        L.fso_quat_to_yaw.argtypes = [C.c_void_p]
+        L.fso_frustum_vertices_2d.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
+        L.fso_point_in_triangle.restype = C.c_int
+        L.fso_point_in_triangle.argtypes = [C.c_double, C.c_double, C.c_void_p]
+        L.fso_frustum_overlap.restype = C.c_int
+        L.fso_frustum_overlap.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.fso_information_of_point_affine.restype = C.c_float
+        L.fso_information_of_point_affine.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        L.fso_information_for_pose.restype = C.c_int
+        L.fso_information_for_pose.argtypes = [C.POINTER(_Grid), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.POINTER(_KfParams), C.c_int] + [C.c_void_p] * 4
         L.fso_u1_costs.restype = C.c_int
         L.fso_u1_costs.argtypes = [C.c_int32] + [C.c_void_p] * 5 + [C.c_double] * 5 + [C.c_void_p] * 3
         _lib = L
@@ -259,6 +276,56 @@ def information_frontier_pair(landmarks_xyz, est_pose7, tri) -> float:
     a = np.ascontiguousarray(est_pose7, dtype=np.float64)
     t = np.ascontiguousarray(tri, dtype=np.float64).reshape(6)
     return float(lib().fso_information_frontier_pair(_p(lm), lm.shape[0], _p(a), _p(t)))
+
+
+def quat_to_yaw(q_xyzw) -> float:
+    a = np.ascontiguousarray(q_xyzw, dtype=np.float64)
+    return float(lib().fso_quat_to_yaw(_p(a)))
+
+
+def frustum_vertices_2d(pose7, max_depth, hfov) -> np.ndarray:
+    a = np.ascontiguousarray(pose7, dtype=np.float64)
+    t = np.zeros(6, dtype=np.float64)
+    lib().fso_frustum_vertices_2d(_p(a), float(max_depth), float(hfov), _p(t))
+    return t
+
+
+def point_in_triangle(px, py, tri) -> bool:
+    t = np.ascontiguousarray(tri, dtype=np.float64).reshape(6)
+    return bool(lib().fso_point_in_triangle(float(px), float(py), _p(t)))
+
+
+def frustum_overlap(cur_pose7, check_pose7, max_depth, hfov, err) -> bool:
+    a = np.ascontiguousarray(cur_pose7, dtype=np.float64)
+    b = np.ascontiguousarray(check_pose7, dtype=np.float64)
+    return bool(lib().fso_frustum_overlap(_p(a), _p(b), float(max_depth), float(hfov), float(err)))
+
+
+def information_of_point_affine(pose7, p_w, q_diag=0.01) -> float:
+    a = np.ascontiguousarray(pose7, dtype=np.float64)
+    b = np.ascontiguousarray(p_w, dtype=np.float32)
+    return float(lib().fso_information_of_point_affine(_p(a), _p(b), float(np.float32(q_diag))))
+
+
+def information_for_pose(grid: Grid, pose7, kf_pose7, kf_offsets, points_xyz, max_depth=2.0, hfov=1.089,
+                         max_depth_error=0.5, q_diag=0.01, radius=4.5, n_threads=1) -> dict:
+    """computeInformationForPose for a batch of poses."""
+    pose = np.ascontiguousarray(pose7, dtype=np.float64).reshape(-1, 7)
+    kf = np.ascontiguousarray(kf_pose7, dtype=np.float64).reshape(-1, 7)
+    off = np.ascontiguousarray(kf_offsets, dtype=np.int32)
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float32).reshape(-1, 3)
+    assert off.shape[0] == kf.shape[0] + 1 and off[-1] <= pts.shape[0]
+    n = pose.shape[0]
+    out = {"info_ref": np.zeros(n, np.float32), "info_f64": np.zeros(n, np.float64),
+           "n_cells": np.zeros(n, np.int32), "n_points": np.zeros(n, np.int32)}
+    g = grid.c()
+    prm = _KfParams(float(max_depth), float(hfov), float(max_depth_error), float(np.float32(q_diag)), float(radius))
+    rc = lib().fso_information_for_pose(C.byref(g), n, _p(pose), kf.shape[0], _p(kf), _p(off), _p(pts), C.byref(prm),
+                                        int(n_threads), _p(out["info_ref"]), _p(out["info_f64"]), _p(out["n_cells"]),
+                                        _p(out["n_points"]))
+    if rc != 0:
+        raise RuntimeError(f"fso_information_for_pose failed: {rc}")
+    return out
 
 
 def fim_point_local_f64(p) -> np.ndarray:

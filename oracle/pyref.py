@@ -299,3 +299,96 @@ def pose_information(table, landmarks, pose7, max_dist=14.0, max_angle=1.0):
         info = f32(float(table[key]) * float(crowding_factor(counts[key])))
         total = f32(total + info)
     return dict(info_ref=total, n_visible=nvis, n_voxels=len(counts))
+
+
+# ---------------------------------------------------------------- key-frame pose information (§8a row a24)
+# DEP/include/frontier_exploration/deprecated/util.hpp:49-66,77-119,134-185,616-632,687-759,840-916
+
+def quat_to_yaw(q):
+    """quatToEuler(...)[2]: tf2::Matrix3x3(q).getRPY (tf2 restated from upstream; third party)."""
+    x, y, z, w = (float(v) for v in q)
+    s = 2.0 / (x * x + y * y + z * z + w * w)
+    m00 = 1.0 - (y * (y * s) + z * (z * s))
+    m10 = x * (y * s) + w * (z * s)
+    m20 = x * (z * s) - w * (y * s)
+    if abs(m20) >= 1.0:
+        return 0.0
+    pitch = -math.asin(m20)
+    return math.atan2(m10 / math.cos(pitch), m00 / math.cos(pitch))
+
+
+def frustum_vertices_2d(pose7, depth, hfov):
+    yaw = quat_to_yaw(pose7[3:7])
+    x, y = float(pose7[0]), float(pose7[1])
+    return [(x, y),
+            (x + depth * math.cos(yaw - hfov / 2), y + depth * math.sin(yaw - hfov / 2)),
+            (x + depth * math.cos(yaw + hfov / 2), y + depth * math.sin(yaw + hfov / 2))]
+
+
+def point_in_triangle(p, tri):
+    v0 = (tri[2][0] - tri[0][0], tri[2][1] - tri[0][1])
+    v1 = (tri[1][0] - tri[0][0], tri[1][1] - tri[0][1])
+    v2 = (p[0] - tri[0][0], p[1] - tri[0][1])
+    d00 = v0[0] * v0[0] + v0[1] * v0[1]
+    d01 = v0[0] * v1[0] + v0[1] * v1[1]
+    d02 = v0[0] * v2[0] + v0[1] * v2[1]
+    d11 = v1[0] * v1[0] + v1[1] * v1[1]
+    d12 = v1[0] * v2[0] + v1[1] * v2[1]
+    den = d00 * d11 - d01 * d01
+    if den == 0.0:
+        return False                    # 1/0 = inf -> inf * x is inf/NaN: every comparison chain fails or u + v <= 1 fails
+    inv = 1.0 / den
+    u = (d11 * d02 - d01 * d12) * inv
+    v = (d00 * d12 - d01 * d02) * inv
+    return u >= 0.0 and v >= 0.0 and u + v <= 1.0
+
+
+def frustum_overlap(cur, chk, depth, hfov, err):
+    tri = frustum_vertices_2d(cur, depth + err, hfov)
+    v = frustum_vertices_2d(chk, depth + err, hfov)
+    pts = list(v) + [((v[0][0] + v[1][0]) / 2, (v[0][1] + v[1][1]) / 2),
+                     ((v[1][0] + v[2][0]) / 2, (v[1][1] + v[2][1]) / 2),
+                     ((v[2][0] + v[0][0]) / 2, (v[2][1] + v[0][1]) / 2)]
+    return any(point_in_triangle(p, tri) for p in pts)
+
+
+def info_point_affine(pose7, p_w, q=0.01):
+    """affine computeInformationOfPoint(p_c, p_w, T_w_c_est, Q) (util.hpp:687-759) with numpy float32 matrices."""
+    t = np.array(pose7[:3], dtype=f32)
+    R = quat_to_rot_f32(pose7[3:7])
+    w = np.array(p_w, dtype=f32)
+    p = world_to_camera(R, t, w)
+    n = f32(np.sqrt(f32(p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]))
+    A = (f32(1) / n) * np.eye(3, dtype=f32) - np.outer((f32(1) / (n * n * n)) * p, p).astype(f32)
+    S = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=f32)
+    right = np.concatenate([np.eye(3, dtype=f32), f32(-1.0) * S], axis=1)
+    J = (A @ (R.T @ right)).astype(f32)
+    qf = f32(q)
+    qinv = (qf * qf) * (f32(1) / (qf * (qf * qf)))
+    F = (J.T * qinv) @ J
+    return f32(np.trace(F))
+
+
+def information_for_pose(cm: Costmap, pose7, kf_pose7, kf_points, depth=2.0, hfov=1.089, err=0.5, q=0.01, radius=4.5):
+    """computeInformationForPose (util.hpp:840-916); kf_points: one (m_k, 3) array per key-frame."""
+    tri = frustum_vertices_2d(pose7, depth, hfov)
+    info_map = {}
+    total = f32(0)
+    n_points = 0
+    for kp, pts in zip(kf_pose7, kf_points):
+        if radius >= 0 and not math.sqrt((kp[0] - pose7[0]) ** 2 + (kp[1] - pose7[1]) ** 2) <= radius:
+            continue
+        if not frustum_overlap(pose7, kp, depth, hfov, err):
+            continue
+        for w in np.asarray(pts, dtype=f32).reshape(-1, 3):
+            if not point_in_triangle((float(w[0]), float(w[1])), tri):
+                continue
+            m = cm.world_to_map(float(w[0]), float(w[1]), cm.oz)
+            if m is None:
+                continue
+            idx = m[1] * cm.nx + m[0]
+            if idx not in info_map:
+                info_map[idx] = info_point_affine(pose7, w, q)
+            total = f32(total + info_map[idx])
+            n_points += 1
+    return float(total), len(info_map), n_points

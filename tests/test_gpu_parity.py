@@ -363,3 +363,56 @@ def test_information_frontier_pair(fs, oracle, scorer):
     want = np.array([oracle.information_frontier_pair(w.landmarks, poses[i], tris[i]) for i in range(30)])
     assert (want > 0).sum() > 10
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+def _yaw_poses(xy, yaw):
+    p = np.zeros((len(yaw), 7))
+    p[:, :2] = xy
+    p[:, 5] = np.sin(np.asarray(yaw) / 2)
+    p[:, 6] = np.cos(np.asarray(yaw) / 2)
+    return p
+
+
+def test_information_for_pose_matches_oracle(fs, oracle, scorer):
+    """Row a24: counts bit-exact, information within 1e-4 of the float64 form (and of the reference's float32 sum)."""
+    w = fs.synth.make_small_2d(21, n=128, n_cand=200, n_landmarks=4000)
+    kf_pose, off, pts = fs.synth.make_keyframes(w, 300, seed=5, points_per_kf=250, reach=3.0)   # > 256: two key-frame rounds
+    g = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
+    scorer.upload_grid(w.cells, w.origin, w.resolution)
+    scorer.upload_keyframes(kf_pose, off, pts)
+    rng = np.random.default_rng(2)
+    poses = _yaw_poses(w.goals[:, :2], rng.uniform(-np.pi, np.pi, size=w.goals.shape[0]))
+    for kw in (dict(), dict(radius=-1.0), dict(max_depth=1.0, hfov=0.6, max_depth_error=0.0, q_diag=1.0, radius=2.0)):
+        got = scorer.information_for_pose(poses, **kw)
+        want = oracle.information_for_pose(g, poses, kf_pose, off, pts, n_threads=4, **kw)
+        assert want["n_points"].sum() > 1000
+        np.testing.assert_array_equal(got["n_cells"], want["n_cells"])
+        np.testing.assert_array_equal(got["n_points"], want["n_points"])
+        np.testing.assert_allclose(got["information"], want["info_f64"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(got["information"], want["info_ref"], rtol=1e-4, atol=1e-6)
+    # no key-frames at all
+    scorer.upload_keyframes(np.zeros((0, 7)), [0], np.zeros((0, 3), np.float32))
+    e = scorer.information_for_pose(poses[:5])
+    assert not e["information"].any() and not e["n_cells"].any()
+
+
+def test_information_for_pose_hbm_table_pass(fs, oracle, scorer):
+    """A FOV triangle covering more cells than the LDS table holds is redone with the HBM table: same results."""
+    n = 256
+    cells = np.zeros((1, n, n), np.uint8)
+    origin = (-6.4, -6.4, 0.0)
+    rng = np.random.default_rng(9)
+    pts = np.concatenate([rng.uniform(-6.3, 6.3, size=(60000, 2)), rng.uniform(0.0, 2.0, size=(60000, 1))], axis=1).astype(np.float32)
+    kf_pose = _yaw_poses(rng.uniform(-3, 3, size=(30, 2)), rng.uniform(-np.pi, np.pi, size=30))
+    off = np.arange(0, 60001, 2000, dtype=np.int32)
+    g = oracle.Grid(cells, origin=origin, resolution=0.05)
+    scorer.upload_grid(cells, origin, 0.05)
+    scorer.upload_keyframes(kf_pose, off, pts)
+    poses = _yaw_poses(rng.uniform(-2, 2, size=(12, 2)), rng.uniform(-np.pi, np.pi, size=12))
+    kw = dict(max_depth=6.0, hfov=2.0, max_depth_error=0.5, radius=-1.0)
+    got = scorer.information_for_pose(poses, **kw)
+    want = oracle.information_for_pose(g, poses, kf_pose, off, pts, n_threads=4, **kw)
+    assert want["n_cells"].max() > 3072                       # beyond 3/4 of the 4096-slot LDS table
+    np.testing.assert_array_equal(got["n_cells"], want["n_cells"])
+    np.testing.assert_array_equal(got["n_points"], want["n_points"])
+    np.testing.assert_allclose(got["information"], want["info_f64"], rtol=1e-4, atol=1e-6)

@@ -67,7 +67,7 @@ def test_get_frontier_costs_and_pose_safety(fs, oracle, ref_table, tmp_path):
     print(p.stdout, p.stderr)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DID NOT THROW" not in p.stdout and "failures: 0" in p.stdout
-    got = np.fromfile(out, dtype=np.float64).reshape(-1, 8)
+    got = np.fromfile(out, dtype=np.float64).reshape(-1, 9)
 
     G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
     P = oracle.RayParams(polygon=poly32)
@@ -94,3 +94,11 @@ def test_get_frontier_costs_and_pose_safety(fs, oracle, ref_table, tmp_path):
     fim = oracle.pose_information(ref_table, w.landmarks, oracle.poses_from_yaw(w.goals, arr["yaw"]), 14.0, 1.0)
     sc = np.maximum(np.abs(fim["info_f64"]), 1e-6)
     assert np.max(np.abs(got[:, 7] - fim["info_f64"]) / sc) <= 1e-4
+    # computeInformationForPoses: the first 20 poses are the key-frames, landmark j belongs to key-frame j % 20
+    poses = oracle.poses_from_yaw(w.goals, arr["yaw"])
+    n_kf = min(20, n)
+    per_kf = [w.landmarks[k::n_kf] for k in range(n_kf)]
+    off = np.concatenate([[0], np.cumsum([len(p) for p in per_kf])]).astype(np.int32)
+    kf = oracle.information_for_pose(G, poses, poses[:n_kf], off, np.concatenate(per_kf), 2.0, 1.089, 0.5, 0.01, 4.5)
+    assert kf["n_points"].sum() > 100
+    np.testing.assert_allclose(got[:, 8], kf["info_f64"], rtol=1e-4, atol=1e-6)
