@@ -33,9 +33,10 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C3", help="C3 (headline) | C2 | C1 (smaller, for rehearsal)")
+    ap.add_argument("--depth-cells", type=int, default=0, help="ray length L in cells (0: the config's 40 = 2 m; BASELINE.md's secondary throughput run uses 160)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time; 0 disables")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the measured configuration) | gloo (rehearsal of the N > 1 path on one GPU: ranks share the device, records are gathered through host memory)")
@@ -119,6 +120,8 @@ def main():
     per_rank = cfg["n_cand"]
     n_total = per_rank * world
     w = fs.synth.make_workload(args.workload, n_cand=n_total)
+    if args.depth_cells > 0:
+        w.max_camera_depth = args.depth_cells * w.resolution
     lo, hi = shard.shard_bounds(n_total, world, rank)
     cap = shard.shard_capacity(n_total, world)
 
@@ -188,14 +191,15 @@ def main():
         b_ray = R * E * (L + 1) + (2 * r_fp + 1) ** 2
         n_chunks = -(-m // 64)
         b_fim = m_tested * 12 + n_chunks * 16 + 32
+        launches_per_step = fim_n / max(1, args.steps)
         fim_avg_s = (fim_ms / max(fim_n, 1)) * 1e-3
-        achieved = (n_local * b_fim) / fim_avg_s / 1e9 if fim_n else None
+        achieved = (n_local * b_fim / max(launches_per_step, 1e-9)) / fim_avg_s / 1e9 if fim_n else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload:
+                if tj.get("workload") == args.workload and args.depth_cells in (0, 40):
                     traffic = tj.get("fs_fim_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -215,14 +219,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "fs_fim_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_candidate": b_fim, "m_tested_per_candidate": m_tested,
-                         "bruteforce_bytes_per_candidate": m * 12 + 32, "candidates_per_launch": n_local,
+                         "bruteforce_bytes_per_candidate": m * 12 + 32, "candidates_per_launch": n_local / max(launches_per_step, 1e-9),
+                         "launches_per_step": launches_per_step,
                          "hash_tier2_candidates": tier2, "hash_tier3_candidates": tier3,
                          "avg_launch_ms": fim_ms / max(fim_n, 1), "launches": fim_n,
                          "note": "algorithmic bytes (SURVEY 8(d), M_tested measured) / hipEvent time; the landmark cloud is "
                                  "served from L2 after the first touch, so algorithmic GB/s is not HBM traffic (see traffic)"},
-            "kernels_ms_per_step": {"fs_raymarch_kernel": ray_ms / max(ray_n, 1), "fs_fim_kernel": fim_ms / max(fim_n, 1),
-                                    "fs_fim_overflow_kernel": ovf_ms / max(ovf_n, 1),
-                                    "raymarch_algorithmic_GBps": (n_local * b_ray) / ((ray_ms / max(ray_n, 1)) * 1e-3) / 1e9 if ray_n else None},
+            "kernels_ms_per_step": {"fs_raymarch_kernel": ray_ms / args.steps, "fs_fim_kernel": fim_ms / args.steps,
+                                    "fs_fim_overflow_kernel": ovf_ms / args.steps,
+                                    "raymarch_algorithmic_GBps": (n_local * b_ray) / ((ray_ms / args.steps) * 1e-3) / 1e9 if ray_n else None},
             "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)

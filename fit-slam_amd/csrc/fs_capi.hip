@@ -171,18 +171,19 @@ struct ScopedTimer {
     fs_ctx *c;
     TimedLaunch t{};
     bool on;
-    ScopedTimer(fs_ctx *ctx, int kind) : c(ctx), on(ctx->timing)
+    hipStream_t s;
+    ScopedTimer(fs_ctx *ctx, int kind, hipStream_t stream = nullptr) : c(ctx), on(ctx->timing), s(stream ? stream : ctx->stream)
     {
         if (!on) return;
         t.kind = kind;
         t.start = get_event(c);
         t.stop = get_event(c);
-        (void)hipEventRecord(t.start, c->stream);
+        (void)hipEventRecord(t.start, s);
     }
     ~ScopedTimer()
     {
         if (!on) return;
-        (void)hipEventRecord(t.stop, c->stream);
+        (void)hipEventRecord(t.stop, s);
         c->launches.push_back(t);
     }
 };
@@ -1042,17 +1043,26 @@ int fs_set_fim_params(fs_ctx *c, const fs_fim_params *p)
     return FS_OK;
 }
 
-static int run_fim(fs_ctx *c, FsFimArgs &a)
+static void bind_fim_outputs(fs_ctx *c, FsFimArgs &a)
 {
     a.info_ref = c->d_info.p; a.trace = c->d_trace.p; a.logdet = c->d_logdet.p;
     a.n_visible = c->d_nvis.p; a.n_voxels = c->d_nvox.p; a.overflow = c->d_overflow.p;
     a.sums = c->d_sums.p;
     a.tested = c->d_tested.p;
     a.flagged = c->d_flagged.p;
-    {
-        ScopedTimer t(c, 1);
-        FS_HIP(c, fs_launch_fim(a, c->stream));
-    }
+}
+
+// tier 1 on candidates [lo, lo + count) of the processing order
+static int run_fim_tier1(fs_ctx *c, FsFimArgs &a, const int32_t *perm, int32_t lo, int32_t count)
+{
+    a.cand_perm = perm; a.cand_lo = lo; a.cand_count = count;
+    ScopedTimer t(c, 1);
+    FS_HIP(c, fs_launch_fim(a, c->stream));
+    return FS_OK;
+}
+
+static int run_fim_rest(fs_ctx *c, FsFimArgs &a)
+{
     {
         // tiers 2 and 3 exit at once unless the previous tier flagged a candidate (device-side counters)
         ScopedTimer t(c, 2);
@@ -1060,6 +1070,14 @@ static int run_fim(fs_ctx *c, FsFimArgs &a)
     }
     FS_HIP(c, fs_launch_fim_finish(a, c->stream));
     return FS_OK;
+}
+
+static int run_fim(fs_ctx *c, FsFimArgs &a)
+{
+    bind_fim_outputs(c, a);
+    int rc = run_fim_tier1(c, a, nullptr, 0, a.n);
+    if (rc) return rc;
+    return run_fim_rest(c, a);
 }
 
 int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, float *fim21,
@@ -1259,16 +1277,20 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     ra.yawR = c->d_yawR.p; ra.pose12 = c->d_Rt.p;
     rc = maybe_sort(c, ra);
     if (rc) return rc;
-    {
-        ScopedTimer t(c, 0);
-        FS_HIP(c, fs_launch_raymarch(ra, c->stream));
-    }
     FsFimArgs fa{};
     fill_fim_args(c, fa);
     fa.n = n; fa.Rt = c->d_Rt.p;
     fa.status = c->d_status.p;
     fa.fim21 = nullptr;
-    rc = run_fim(c, fa);
+    bind_fim_outputs(c, fa);
+    {
+        ScopedTimer t(c, 0);
+        FS_HIP(c, fs_launch_raymarch(ra, c->stream));
+    }
+    // the FIM kernel visits the candidates in the same spatial order: neighbouring poses walk the same landmark chunks
+    rc = run_fim_tier1(c, fa, ra.perm, 0, n);
+    if (rc) return rc;
+    rc = run_fim_rest(c, fa);
     if (rc) return rc;
     FsPackArgs pa{};
     pa.n = n;

@@ -404,8 +404,8 @@ __global__ __launch_bounds__(THREADS)
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    const int c = blockIdx.x;
-    if (c >= a.n) return;
+    if ((int)blockIdx.x >= a.cand_count) return;
+    const int c = a.cand_perm ? a.cand_perm[a.cand_lo + (int)blockIdx.x] : a.cand_lo + (int)blockIdx.x;
     if (a.status && a.status[c] != FS_STATUS_OK) {           // blacklisted / off-map candidates carry zero FI
         zero_sums(a, c);
         return;
@@ -541,12 +541,12 @@ hipError_t allow_lds(K kernel, size_t bytes)
 
 hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
-    if (a0.n <= 0) return hipSuccess;
+    if (a0.n <= 0 || a0.cand_count <= 0) return hipSuccess;
     FsFimArgs a = a0;
     const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
     hipError_t e = allow_lds(fs_fim_kernel<FS_T1_THREADS>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fs_fim_kernel<FS_T1_THREADS>, dim3(a.n), dim3(FS_T1_THREADS), lds, s, a);
+    hipLaunchKernelGGL(fs_fim_kernel<FS_T1_THREADS>, dim3(a.cand_count), dim3(FS_T1_THREADS), lds, s, a);
     return hipGetLastError();
 }
 

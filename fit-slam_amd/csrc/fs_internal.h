@@ -112,6 +112,10 @@ struct FsFimArgs {
     int32_t n;
     const float *Rt;
     const int32_t *status;     // [n] or nullptr: status != 0 -> zero FI
+    // tier 1 may be launched on a slice of the (spatially ordered) candidate list: workgroup b scores candidate
+    // cand_perm[cand_lo + b] (cand_perm == nullptr: cand_lo + b), b < cand_count
+    const int32_t *cand_perm;
+    int32_t cand_lo, cand_count;
     // outputs (device)
     float *info_ref, *trace, *logdet, *fim21;   // fim21 may be nullptr
     int32_t *n_visible, *n_voxels;
