@@ -77,7 +77,7 @@ struct fs_ctx {
     DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
     bool opt_cull = true;
     int opt_bits1 = 14;            // development knobs (fs_set_option "fim.bits1", "fim.skip32")
-    int opt_skip32 = 15;
+    int opt_skip32 = 12;
     DevBuf<unsigned long long> d_counters;
 
     // lookup table
@@ -414,6 +414,8 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     while (bits < c->opt_bits1 && (1 << bits) < 2 * c->m) ++bits;
     a.hash_bits = bits;
     a.hash_bits2 = ((1 << bits) < 2 * c->m) ? 15 : bits;
+    // very large clouds: the tier's double-buffered chunk masks no longer fit next to its 128-KiB table -> HBM tier directly
+    if (a.hash_bits2 > bits && fs_fim_tier2_lds_bytes(a.hash_bits2, c->n_chunks) > 160 * 1024) a.hash_bits2 = bits;
     a.fail_code1 = (a.hash_bits2 > a.hash_bits) ? 1u : 2u;
     a.skip32 = c->opt_skip32;
     a.gtable = c->d_gtable.p;
@@ -851,7 +853,7 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
 {
     if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    // the per-wave chunk masks of the 1024-thread tier must fit the CU's LDS next to its 128-KiB table
+    // chunk masks live in LDS (two buffers of one bit per chunk and wave pass) next to the 64-KiB tier-1 table
     if (m > 2000000) return fail(c, FS_E_INVALID, "at most 2,000,000 landmarks per context");
     // Morton order (10 bits per axis inside the cloud's bounding box) so that 64 consecutive landmarks
     // are spatial neighbours; non-finite points sort last.
@@ -927,8 +929,8 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
     c->ghash_bits = gb;
     FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
     if (!c->d_counters.p) {
-        FS_HIP(c, c->d_counters.ensure(8));
-        FS_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 8 * sizeof(unsigned long long), c->stream));
+        FS_HIP(c, c->d_counters.ensure(16));
+        FS_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 16 * sizeof(unsigned long long), c->stream));
         FS_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->have_lm = true;

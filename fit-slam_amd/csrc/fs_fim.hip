@@ -156,280 +156,299 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
     return v;
 }
 
-// dynamic-LDS carve-up of one workgroup: [per-wave compaction queues][hash table]
+// dynamic-LDS carve-up of one workgroup: [per-wave compaction queues][factor copy][2 x chunk masks][hash table]
 template <int THREADS>
 struct Lds {
     static constexpr int WAVES = THREADS / 64;
-    static constexpr size_t fixed_words = (size_t)WAVES * 3 * FS_QCAP + FS_FACTOR_N;   // + 2 * WAVES * n_groups mask words, then the table
-    static __device__ __forceinline__ unsigned long long *masks(uint32_t *base, int) { return reinterpret_cast<unsigned long long *>(base + fixed_words); }
+    static constexpr size_t fixed_words = (size_t)WAVES * 3 * FS_QCAP + FS_FACTOR_N;
+    // two mask buffers (the next candidate is culled while the current one is still being scored)
+    static __host__ __device__ size_t mask_words(int n_groups) { const size_t w = 4 * (size_t)WAVES * n_groups; return w + (w & 2); }
+    static __device__ __forceinline__ unsigned long long *masks(uint32_t *base, int n_groups, int buf)
+    {
+        return reinterpret_cast<unsigned long long *>(base + fixed_words) + (size_t)buf * WAVES * n_groups;
+    }
     static __device__ __forceinline__ float *factor(uint32_t *base) { return reinterpret_cast<float *>(base) + WAVES * 3 * FS_QCAP; }
     static __device__ __forceinline__ float *queue(uint32_t *base, int wave) { return reinterpret_cast<float *>(base) + wave * (3 * FS_QCAP); }
-    static __device__ __forceinline__ uint32_t *table(uint32_t *base, int n_groups) { return base + fixed_words + 2 * WAVES * n_groups + ((2 * WAVES * n_groups) & 2); }
+    static __device__ __forceinline__ uint32_t *table(uint32_t *base, int n_groups) { return base + fixed_words + mask_words(n_groups); }
 };
 
+// The work of one persistent workgroup: items [0, count) of a list, handed out by a device-side counter.
+struct FimWork {
+    const int32_t *list;          // item -> candidate (nullptr: lo + item)
+    int32_t lo, count;
+    unsigned long long *counter;
+};
+
+// Scores candidates until the work list is empty.  The loop is software-pipelined ACROSS candidates: a wave that has
+// finished its share of candidate i culls the chunks of candidate i+1 before it joins the reduction barrier, so the
+// latency of the sphere loads and the imbalance between waves overlap instead of adding up.  Two barriers per
+// candidate: after the table clear and after the reduction.
 template <int THREADS, bool GLOBAL_TABLE>
-__device__ __forceinline__ void fim_candidate(const FsFimArgs &a, int c, uint32_t *lds, uint32_t *table, int bits,
-                                              uint32_t fail_code, bool last_use)
+__device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits,
+                                           const uint32_t fail_code)
 {
     constexpr int WAVES = THREADS / 64;
-    const uint32_t max_probe = GLOBAL_TABLE ? (1u << bits) : FS_MAX_PROBE;   // bucket visits incl. re-reads
-    const int tier_bits = bits;
+    constexpr int STRIDE = WAVES * 64;
+    const uint32_t max_probe = GLOBAL_TABLE ? (1u << tier_bits) : FS_MAX_PROBE;   // bucket visits incl. re-reads
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    __shared__ int sh_overflow, sh_nvox, sh_wave_tested[WAVES];
+    __shared__ int sh_overflow[2], sh_nvox[2], sh_wave_tested[2][WAVES], sh_next[2];
     __shared__ float sh_red[WAVES * FS_NACC];
 
-    // ---- pose
-    float R[9], t[3];
-    {
-        const float4 *p4 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c);
-        const float4 r0 = p4[0], r1 = p4[1], r2 = p4[2];
-        R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
-        R[8] = r2.x; t[0] = r2.y; t[1] = r2.z; t[2] = r2.w;
-    }
-
-    // px = ax*dx + ay*dy + az*dz: the camera's +x axis in the world frame
-    const float ax = R[0], ay = R[3], az = R[6];
     const float4 *__restrict__ spheres = reinterpret_cast<const float4 *>(a.spheres);
     const float *__restrict__ LX = a.lx, *__restrict__ LY = a.ly, *__restrict__ LZ = a.lz;
-    constexpr int STRIDE = WAVES * 64;
-    unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
-
-    // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass.
-    // All passes are issued before the table is cleared so that their latency overlaps the clear.
-    int tested = 0;                                            // wave-uniform: chunks this wave will scan
-    auto cull_one = [&](int j, const float4 s) -> bool {
-        bool keep = j < a.n_chunks;
-        if (keep && a.cull) {
-            const float dx = s.x - t[0], dy = s.y - t[1], dz = s.z - t[2];   // s.w carries a safety margin: conservative
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            const float reach = a.max_dist_f + s.w;
-            keep = d2 <= reach * reach;
-            if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
-                // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|)
-                const float dist = sqrtf(d2);
-                const float sb = s.w / dist;                           // < 1 here
-                const float cb = sqrtf(fmaxf(0.0f, 1.0f - sb * sb));
-                const float cab = a.cos_a * cb - a.sin_a * sb;          // cos(alpha + beta)
-                const float dot = dx * ax + dy * ay + dz * az;
-                keep = dot >= dist * cab - 1.0e-4f * dist - 1.0e-4f;
-            }
-        }
-        return keep;
-    };
-    for (int gb = 0; gb < a.n_groups; gb += 4) {
-        // four sphere loads in flight per lane (one latency for up to 2048 chunks per 512-thread workgroup)
-        float4 sp[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = (gb + u) * STRIDE + lane * WAVES + wave;
-            sp[u] = (gb + u < a.n_groups && j < a.n_chunks) ? spheres[j] : make_float4(0.f, 0.f, 0.f, -1.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (gb + u < a.n_groups) {
-                const int j = (gb + u) * STRIDE + lane * WAVES + wave;
-                const unsigned long long mask = __ballot(cull_one(j, sp[u]));
-                tested += __popcll(mask);
-                if (lane == 0) masks[gb + u] = mask;
-            }
-        }
-    }
-
-    // chunks accepted by the whole workgroup: every wave publishes its count, one barrier, everyone sums
-    if (lane == 0) sh_wave_tested[wave] = tested;
-    if (tid == 0) { sh_overflow = 0; sh_nvox = 0; }
     float *lfac = Lds<THREADS>::factor(lds);
+    float *qx = Lds<THREADS>::queue(lds, wave), *qy = qx + FS_QCAP, *qz = qy + FS_QCAP;
+
+    auto fetch = [&]() -> int {                                    // thread 0 only
+        const int i = (int)atomicAdd(work.counter, 1ull);
+        if (i >= work.count) return -1;
+        return work.list ? work.list[work.lo + i] : work.lo + i;
+    };
+
+    // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass, four
+    // sphere loads in flight per lane.  Blacklisted / off-map candidates keep nothing: zero FI.
+    auto cull = [&](int c, int buf) {
+        unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups, buf) + wave * a.n_groups;
+        const bool dead = a.status && a.status[c] != FS_STATUS_OK;
+        const float4 r0 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[0];
+        const float4 r1 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[1];
+        const float4 r2 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[2];
+        const float ax = r0.x, ay = r0.w, az = r1.z;               // the camera's +x axis in the world frame (R[0], R[3], R[6])
+        const float t0 = r2.y, t1 = r2.z, t2 = r2.w;
+        int tested = 0;
+        auto cull_one = [&](int j, const float4 s) -> bool {
+            bool keep = j < a.n_chunks && !dead;
+            if (keep && a.cull) {
+                const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;   // s.w carries a safety margin: conservative
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float reach = a.max_dist_f + s.w;
+                keep = d2 <= reach * reach;
+                if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
+                    // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|)
+                    const float dist = sqrtf(d2);
+                    const float sb = s.w / dist;                           // < 1 here
+                    const float cb = sqrtf(fmaxf(0.0f, 1.0f - sb * sb));
+                    const float cab = a.cos_a * cb - a.sin_a * sb;          // cos(alpha + beta)
+                    const float dot = dx * ax + dy * ay + dz * az;
+                    keep = dot >= dist * cab - 1.0e-4f * dist - 1.0e-4f;
+                }
+            }
+            return keep;
+        };
+        for (int gb = 0; gb < a.n_groups; gb += 4) {
+            float4 sp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = (gb + u) * STRIDE + lane * WAVES + wave;
+                sp[u] = (gb + u < a.n_groups && j < a.n_chunks) ? spheres[j] : make_float4(0.f, 0.f, 0.f, -1.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (gb + u < a.n_groups) {
+                    const int j = (gb + u) * STRIDE + lane * WAVES + wave;
+                    const unsigned long long mask = __ballot(cull_one(j, sp[u]));
+                    tested += __popcll(mask);
+                    if (lane == 0) masks[gb + u] = mask;
+                }
+            }
+        }
+        if (lane == 0) sh_wave_tested[buf][wave] = tested;         // chunks this wave will scan
+    };
+
+    // ---- prologue: first candidate, factor table
+    if (tid == 0) { sh_next[0] = fetch(); sh_overflow[0] = 0; sh_overflow[1] = 0; sh_nvox[0] = 0; sh_nvox[1] = 0; }
     for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
     __syncthreads();
-    int wg_tested = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) wg_tested += sh_wave_tested[w];
-
-    // ---- size and clear the hash table.  Distinct voxels are at most ~0.5 of the landmarks scanned (measured
-    // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
-    // candidates clear only a small table.  A candidate that could overfill this tier's largest table
-    // (more than 3/4 full: linear probing crawls) goes straight to the next tier; the running voxel count in the
-    // main loop is the exact safety net.
-    // (only where the next tier is another LDS tier: falling through to the HBM tier by prediction alone is too costly)
-    const bool skip_tier = !GLOBAL_TABLE && fail_code == 1u && ((long long)wg_tested * 64 * a.skip32 > (long long)(3 << (tier_bits - 2)) * 32);
-    if (!GLOBAL_TABLE) {
-        int need = 10;
-        while (need < tier_bits && (1 << need) < wg_tested * 64) ++need;
-        bits = need;
-    }
-    const uint32_t slots = 1u << bits;
-    const int nvox_limit = GLOBAL_TABLE ? 0x7fffffff : (int)((slots >> 2) * 3u);
-    if (!skip_tier) {
-        if (GLOBAL_TABLE) {
-            for (uint32_t i = tid; i < slots; i += THREADS) table[i] = 0u;
-        } else {
-            uint4 *t4 = reinterpret_cast<uint4 *>(table);
-            for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
+    int cur = sh_next[0];
+    int buf = 0;
+    if (cur >= 0) cull(cur, 0);
     __syncthreads();
-    bool overflow = false;
 
-    Acc acc;
-    acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
+    while (cur >= 0) {
+        const int c = cur;
+        if (tid == 0) sh_next[buf ^ 1] = fetch();
+        int wg_tested = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { acc.A[i] = 0.f; acc.B[i] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) acc.s[i] = 0.f;
+        for (int w = 0; w < WAVES; ++w) wg_tested += sh_wave_tested[buf][w];
 
-    float *qx = Lds<THREADS>::queue(lds, wave), *qy = qx + FS_QCAP, *qz = qy + FS_QCAP;
-    int qcount = 0;                                            // wave-uniform
-    volatile int *v_overflow = &sh_overflow;
-    volatile int *v_nvox = &sh_nvox;
-    if (skip_tier) { overflow = true; if (tid == 0) *v_overflow = 1; }
-
-    // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
-    // next chunk's landmarks prefetched into registers while the current one is processed.
-    for (int g = 0; g < a.n_groups && !skip_tier; ++g) {
-        const int g0 = g * STRIDE;
-        unsigned long long mask = masks[g];
-        mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
-               ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
+        // ---- size and clear the hash table.  Distinct voxels are at most ~0.5 of the landmarks scanned (measured
+        // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
+        // candidates clear only a small table.  A candidate predicted to overfill this tier's largest table goes
+        // straight to the next tier (only where that is another LDS tier: falling through to the HBM tier by
+        // prediction alone is too costly); the running voxel count in the main loop is the exact safety net.
+        const bool skip_tier = !GLOBAL_TABLE && fail_code == 1u && ((long long)wg_tested * 64 * a.skip32 > (long long)(3 << (tier_bits - 2)) * 32);
+        int bits = tier_bits;
         if (!GLOBAL_TABLE) {
-            if (*v_overflow) break;                                // another wave ran out of table: the next tier redoes it
-            // distinct voxels so far, extrapolated over the chunks still to come (Morton order interleaved over
-            // the waves makes the prefix representative): a table that clearly will not fit is handed on early
-            if (g > 0 && (long long)(*v_nvox) * a.n_chunks > (long long)nvox_limit * g0 * 5 / 4) { overflow = true; *v_overflow = 1; break; }
+            int need = 10;
+            while (need < tier_bits && (1 << need) < wg_tested * 64) ++need;
+            bits = need;
         }
-        // two chunks in flight ahead of the one being processed
-        auto pop = [&]() -> int {
-            if (!mask) return -1;
-            const int id = g0 + __builtin_ctzll(mask) * WAVES + wave;
-            mask &= mask - 1ull;
-            return id;
-        };
-        int c0 = pop(), c1 = pop();
-        float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
-        if (c0 >= 0) { const int l = c0 * 64 + lane; x0 = LX[l]; y0 = LY[l]; z0 = LZ[l]; }
-        if (c1 >= 0) { const int l = c1 * 64 + lane; x1 = LX[l]; y1 = LY[l]; z1 = LZ[l]; }
-        while (c0 >= 0) {
-            const int c2 = pop();
-            float x2 = 0.f, y2 = 0.f, z2 = 0.f;
-            if (c2 >= 0) { const int l = c2 * 64 + lane; x2 = LX[l]; y2 = LY[l]; z2 = LZ[l]; }
-            // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
-            const float dx = x0 - t[0], dy = y0 - t[1], dz = z0 - t[2];
-            const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
-            const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
-            const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
-            const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
-            bool vis = (n2 <= a.maxd2);
-            if (a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
-            else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px * px <= a.cos2 * n2));
-            // ---- 3. compact
-            const unsigned long long m = __ballot(vis);
-            if (m != 0ull) {
-                if (vis) {
-                    const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    qx[pos] = px; qy[pos] = py; qz[pos] = pz;
-                }
-                qcount += __popcll(m);
-                if (qcount >= 64) {
-                    qcount -= 64;                                  // take the newest 64: the remainder stays in place
-                    const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
-                    // ---- 4. score
-                    const bool opened = score_visible(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
-                    const unsigned long long om = __ballot(opened);
-                    if (!GLOBAL_TABLE && om != 0ull) {
-                        int total = 0;
-                        if (lane == 0) total = atomicAdd(&sh_nvox, (int)__popcll(om)) + (int)__popcll(om);
-                        if (__builtin_amdgcn_readfirstlane(total) > nvox_limit) overflow = true;
-                    }
-                    if (__any(overflow)) *v_overflow = 1;
-                }
+        const uint32_t slots = 1u << bits;
+        const int nvox_limit = GLOBAL_TABLE ? 0x7fffffff : (int)((slots >> 2) * 3u);
+        if (!skip_tier && wg_tested > 0) {
+            if (GLOBAL_TABLE) {
+                for (uint32_t i = tid; i < slots; i += THREADS) table[i] = 0u;
+            } else {
+                uint4 *t4 = reinterpret_cast<uint4 *>(table);
+                for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
             }
-            c0 = c1; x0 = x1; y0 = y1; z0 = z1;
-            c1 = c2; x1 = x2; y1 = y2; z1 = z2;
         }
-    }
-    if (skip_tier) qcount = 0;
-    // flush the queue remainder
-    if (qcount > 0) {
-        const bool have = lane < qcount;
-        score_visible(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
-    }
-    if (overflow) *v_overflow = 1;
+        // ---- pose
+        float R[9], t[3];
+        {
+            const float4 *p4 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c);
+            const float4 r0 = p4[0], r1 = p4[1], r2 = p4[2];
+            R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
+            R[8] = r2.x; t[0] = r2.y; t[1] = r2.z; t[2] = r2.w;
+        }
+        __syncthreads();                                           // table cleared, sh_next published
+        const int nxt = sh_next[buf ^ 1];
+        if (tid == 0) { sh_overflow[buf ^ 1] = 0; sh_nvox[buf ^ 1] = 0; }   // flags of the candidate after this one
+        volatile int *v_overflow = &sh_overflow[buf];
+        volatile int *v_nvox = &sh_nvox[buf];
+        bool overflow = false;
+        if (skip_tier) { overflow = true; if (tid == 0) *v_overflow = 1; }
 
-    // ---- 5. reduce: wave shuffles, then across waves through LDS
-    float vals[FS_NACC];
-    vals[0] = acc.info;
+        Acc acc;
+        acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { vals[1 + i] = acc.A[i]; vals[7 + i] = acc.B[i]; }
+        for (int i = 0; i < 6; ++i) { acc.A[i] = 0.f; acc.B[i] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) vals[13 + i] = acc.s[i];
-    vals[16] = (float)acc.nvis;     // exact: < 2^24 per lane
-    vals[17] = (float)acc.nvox;
-#pragma unroll
-    for (int i = 0; i < FS_NACC; ++i) vals[i] = wave_sum_dpp(vals[i]);
-    if (lane == 63) {
-#pragma unroll
-        for (int i = 0; i < FS_NACC; ++i) sh_red[wave * FS_NACC + i] = vals[i];
-    }
-    __syncthreads();
-    // cross-wave sums in fp64, one thread per quantity; the 6x6 assembly and log det run in
-    // fs_fim_finish_kernel so that this kernel carries no private arrays
-    const bool failed = sh_overflow != 0;
-    if (tid < FS_NACC && !failed) {
-        double x = 0.0;
-        for (int w = 0; w < WAVES; ++w) x += (double)sh_red[w * FS_NACC + tid];
-        a.sums[(size_t)c * FS_NACC + tid] = x;
-    }
-    if (tid == 0) {
-        a.overflow[c] = failed ? fail_code : 0u;                  // the next tier re-scores flagged candidates
-        if (!skip_tier) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u);       // landmarks tested (M_tested), summed by the finish kernel
-        if (failed && fail_code < 3u) {
-            const unsigned long long slot = atomicAdd(&a.counters[fail_code], 1ull);
-            a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
-        } else if (failed) {
-            atomicAdd(&a.counters[3], 1ull);
+        for (int i = 0; i < 3; ++i) acc.s[i] = 0.f;
+        int qcount = 0;                                            // wave-uniform
+        const unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups, buf) + wave * a.n_groups;
+
+        // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
+        // next chunks' landmarks prefetched into registers while the current one is processed.
+        for (int g = 0; g < a.n_groups && !skip_tier; ++g) {
+            const int g0 = g * STRIDE;
+            unsigned long long mask = masks[g];
+            mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
+                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
+            if (!GLOBAL_TABLE) {
+                if (*v_overflow) break;                            // another wave ran out of table: the next tier redoes it
+                // distinct voxels so far, extrapolated over the chunks still to come (Morton order interleaved over
+                // the waves makes the prefix representative): a table that clearly will not fit is handed on early
+                if (g > 0 && (long long)(*v_nvox) * a.n_chunks > (long long)nvox_limit * g0 * 5 / 4) { overflow = true; *v_overflow = 1; break; }
+            }
+            auto pop = [&]() -> int {
+                if (!mask) return -1;
+                const int id = g0 + __builtin_ctzll(mask) * WAVES + wave;
+                mask &= mask - 1ull;
+                return id;
+            };
+            int c0 = pop(), c1 = pop();
+            float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
+            if (c0 >= 0) { const int l = c0 * 64 + lane; x0 = LX[l]; y0 = LY[l]; z0 = LZ[l]; }
+            if (c1 >= 0) { const int l = c1 * 64 + lane; x1 = LX[l]; y1 = LY[l]; z1 = LZ[l]; }
+            while (c0 >= 0) {
+                const int c2 = pop();
+                float x2 = 0.f, y2 = 0.f, z2 = 0.f;
+                if (c2 >= 0) { const int l = c2 * 64 + lane; x2 = LX[l]; y2 = LY[l]; z2 = LZ[l]; }
+                // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
+                const float dx = x0 - t[0], dy = y0 - t[1], dz = z0 - t[2];
+                const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
+                const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
+                const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
+                const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
+                bool vis = (n2 <= a.maxd2);
+                if (a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
+                else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px * px <= a.cos2 * n2));
+                // ---- 3. compact
+                const unsigned long long m = __ballot(vis);
+                if (m != 0ull) {
+                    if (vis) {
+                        const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        qx[pos] = px; qy[pos] = py; qz[pos] = pz;
+                    }
+                    qcount += __popcll(m);
+                    if (qcount >= 64) {
+                        qcount -= 64;                              // take the newest 64: the remainder stays in place
+                        const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
+                        // ---- 4. score
+                        const bool opened = score_visible(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
+                        const unsigned long long om = __ballot(opened);
+                        if (!GLOBAL_TABLE && om != 0ull) {
+                            int total = 0;
+                            if (lane == 0) total = atomicAdd(&sh_nvox[buf], (int)__popcll(om)) + (int)__popcll(om);
+                            if (__builtin_amdgcn_readfirstlane(total) > nvox_limit) overflow = true;
+                        }
+                        if (__any(overflow)) *v_overflow = 1;
+                    }
+                }
+                c0 = c1; x0 = x1; y0 = y1; z0 = z1;
+                c1 = c2; x1 = x2; y1 = y2; z1 = z2;
+            }
         }
+        if (skip_tier) qcount = 0;
+        // flush the queue remainder
+        if (qcount > 0) {
+            const bool have = lane < qcount;
+            score_visible(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
+        }
+        if (overflow) *v_overflow = 1;
+
+        // ---- the next candidate's cull fills the time this wave would otherwise wait for the slower ones
+        if (nxt >= 0) cull(nxt, buf ^ 1);
+
+        // ---- 5. reduce: DPP within the wave, then across waves through LDS
+        float vals[FS_NACC];
+        vals[0] = acc.info;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { vals[1 + i] = acc.A[i]; vals[7 + i] = acc.B[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vals[13 + i] = acc.s[i];
+        vals[16] = (float)acc.nvis;     // exact: < 2^24 per lane
+        vals[17] = (float)acc.nvox;
+#pragma unroll
+        for (int i = 0; i < FS_NACC; ++i) vals[i] = wave_sum_dpp(vals[i]);
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < FS_NACC; ++i) sh_red[wave * FS_NACC + i] = vals[i];
+        }
+        __syncthreads();
+        // cross-wave sums in fp64, one thread per quantity; the 6x6 assembly and log det run in
+        // fs_fim_finish_kernel so that this kernel carries no private arrays
+        const bool failed = sh_overflow[buf] != 0;
+        if (tid < FS_NACC && !failed) {
+            double x = 0.0;
+            for (int w = 0; w < WAVES; ++w) x += (double)sh_red[w * FS_NACC + tid];
+            a.sums[(size_t)c * FS_NACC + tid] = x;
+        }
+        if (tid == 0) {
+            a.overflow[c] = failed ? fail_code : 0u;                  // the next tier re-scores flagged candidates
+            if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u);   // landmarks tested (M_tested), summed by the finish kernel
+            if (failed && fail_code < 3u) {
+                const unsigned long long slot = atomicAdd(&a.counters[fail_code], 1ull);
+                a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
+            } else if (failed) {
+                atomicAdd(&a.counters[3], 1ull);
+            }
+        }
+        cur = nxt;
+        buf ^= 1;
     }
-    if (!last_use) __syncthreads();                                // LDS is reused by the workgroup's next candidate
 }
 
-__device__ __forceinline__ void zero_sums(const FsFimArgs &a, int c)
-{
-    if (threadIdx.x < FS_NACC) a.sums[(size_t)c * FS_NACC + threadIdx.x] = 0.0;
-    if (threadIdx.x == 0) { a.overflow[c] = 0u; }
-}
-
-// tier 1: one workgroup per candidate, 2^hash_bits LDS slots
+// tier 1: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
 template <int THREADS>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    if ((int)blockIdx.x >= a.cand_count) return;
-    const int c = a.cand_perm ? a.cand_perm[a.cand_lo + (int)blockIdx.x] : a.cand_lo + (int)blockIdx.x;
-    if (a.status && a.status[c] != FS_STATUS_OK) {           // blacklisted / off-map candidates carry zero FI
-        zero_sums(a, c);
-        return;
-    }
-    fim_candidate<THREADS, false>(a, c, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits, a.fail_code1, true);
+    const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
+    fim_worker<THREADS, false>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits, a.fail_code1);
 }
 
-// tier 2: candidates tier 1 appended to its work list; persistent workgroups with a larger LDS table pull
-// items from a device-side counter (heavy candidates differ a lot in cost: static striding left a long tail)
+// tier 2: candidates tier 1 appended to its work list, with a larger LDS table
 template <int THREADS>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_tier2_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    __shared__ int sh_item;
-    const int count = (int)a.counters[1];
-    for (;;) {
-        if (threadIdx.x == 0) sh_item = (int)atomicAdd(&a.counters[7], 1ull);
-        __syncthreads();
-        const int i = sh_item;
-        __syncthreads();
-        if (i >= count) break;
-        fim_candidate<THREADS, false>(a, a.flagged[i], fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2, 2u, false);
-    }
+    const FimWork work{a.flagged, 0, (int)a.counters[1], a.counters + 7};
+    fim_worker<THREADS, false>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2, 2u);
 }
 
 // tier 3: candidates on the second work list; table in HBM with 2x the landmark count of slots and unbounded probing
@@ -438,10 +457,9 @@ __global__ __launch_bounds__(THREADS)
 void fs_fim_tier3_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    const int count = (int)a.counters[2];
+    const FimWork work{a.flagged + a.n, 0, (int)a.counters[2], a.counters + 9};
     uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
-    for (int i = blockIdx.x; i < count; i += gridDim.x)
-        fim_candidate<THREADS, true>(a, a.flagged[(size_t)a.n + i], fs_fim_lds, table, a.ghash_bits, 3u, false);
+    fim_worker<THREADS, true>(a, work, fs_fim_lds, table, a.ghash_bits, 3u);
 }
 
 // One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
@@ -458,7 +476,7 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
         a.counters[4] += a.counters[1];
         a.counters[5] += a.counters[2];
         a.counters[6] += a.counters[3];
-        a.counters[1] = 0ull; a.counters[2] = 0ull; a.counters[3] = 0ull; a.counters[7] = 0ull;
+        a.counters[1] = 0ull; a.counters[2] = 0ull; a.counters[3] = 0ull; a.counters[7] = 0ull; a.counters[8] = 0ull; a.counters[9] = 0ull;
     }
     if (c >= a.n) return;
     const double *S = a.sums + (size_t)c * FS_NACC;
@@ -524,8 +542,19 @@ size_t lds_bytes(int hash_bits, bool global_table, int n_chunks, int *n_groups)
 {
     constexpr int WAVES = THREADS / 64;
     *n_groups = (n_chunks + WAVES * 64 - 1) / (WAVES * 64);
-    const size_t mask_words = 2 * (size_t)WAVES * *n_groups + ((2 * WAVES * *n_groups) & 2);   // table stays 16-byte aligned
+    const size_t mask_words = Lds<THREADS>::mask_words(*n_groups);   // table stays 16-byte aligned
     return sizeof(uint32_t) * (Lds<THREADS>::fixed_words + mask_words + (global_table ? 0 : ((size_t)1 << hash_bits)));
+}
+
+// workgroups of `kernel` that are resident on the device at once (persistent grids are launched with exactly that many)
+template <typename K>
+int resident_blocks(K kernel, int threads, size_t lds)
+{
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), threads, lds) != hipSuccess || per_cu <= 0) per_cu = 1;
+    return cus * per_cu;
 }
 
 template <typename K>
@@ -539,6 +568,12 @@ hipError_t allow_lds(K kernel, size_t bytes)
 #define FS_T1_THREADS 512
 #define FS_T2_THREADS 1024
 
+size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks)
+{
+    int groups = 0;
+    return lds_bytes<FS_T2_THREADS>(hash_bits2, false, n_chunks, &groups) + 2048;   // + the worker's static arrays, rounded up
+}
+
 hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
     if (a0.n <= 0 || a0.cand_count <= 0) return hipSuccess;
@@ -546,7 +581,10 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
     const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
     hipError_t e = allow_lds(fs_fim_kernel<FS_T1_THREADS>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fs_fim_kernel<FS_T1_THREADS>, dim3(a.cand_count), dim3(FS_T1_THREADS), lds, s, a);
+    static int resident = 0;                                   // same kernel, same LDS budget class: query once
+    static size_t resident_lds = 0;
+    if (resident == 0 || resident_lds != lds) { resident = resident_blocks(fs_fim_kernel<FS_T1_THREADS>, FS_T1_THREADS, lds); resident_lds = lds; }
+    hipLaunchKernelGGL(fs_fim_kernel<FS_T1_THREADS>, dim3(a.cand_count < resident ? a.cand_count : resident), dim3(FS_T1_THREADS), lds, s, a);
     return hipGetLastError();
 }
 

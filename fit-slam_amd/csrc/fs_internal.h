@@ -123,7 +123,7 @@ struct FsFimArgs {
     uint32_t *overflow;        // [n] tier that must re-score the candidate (0 = done)
     int32_t *flagged;          // [2][n] work lists: candidates tier 1 / tier 2 hand to the next tier
     uint32_t *tested;          // [n] landmark tests spent on the candidate (all tiers); zeroed by the finish kernel
-    unsigned long long *counters;   // [8]: 0 landmarks tested, 1..3 per-call tier failures, 4..6 their running totals
+    unsigned long long *counters;   // [16]: 0 landmarks tested, 1..3 per-call tier failures, 4..6 their running totals, 7/8/9 work-list cursors of tier 2/1/3
     // hash tables
     int32_t hash_bits;         // tier 1 (LDS, 512-thread workgroups)
     int32_t hash_bits2;        // tier 2 (LDS, 1024-thread workgroups); <= hash_bits disables the tier
@@ -160,6 +160,6 @@ hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_pack(const FsPackArgs &a, hipStream_t s);
 hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hipStream_t s);
-size_t fs_fim_lds_bytes(int hash_bits);
+size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks);   // dynamic + static LDS of the 1024-thread tier
 
 #endif
