@@ -929,8 +929,8 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
     c->ghash_bits = gb;
     FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
     if (!c->d_counters.p) {
-        FS_HIP(c, c->d_counters.ensure(16));
-        FS_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 16 * sizeof(unsigned long long), c->stream));
+        FS_HIP(c, c->d_counters.ensure(32));
+        FS_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(unsigned long long), c->stream));
         FS_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->have_lm = true;
@@ -949,7 +949,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
 
 int fs_get_counter(fs_ctx *c, int which, int64_t *value, int reset)
 {
-    if (!c || !value || which < 0 || which > 7) return FS_E_INVALID;
+    if (!c || !value || which < 0 || which > 31) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
     *value = 0;
     if (!c->d_counters.p) return FS_OK;

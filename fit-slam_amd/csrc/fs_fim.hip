@@ -34,6 +34,12 @@
 #define FS_QCAP 128      // per-wave compaction queue (<= 63 left over + 64 new)
 #define FS_MAX_PROBE 32  // LDS tiers give up (-> next tier) after this many bucket visits
 
+#ifdef FS_FIM_STAMPS   // development: per-phase cycle counters of the tier-1 worker (tools/fim_stamps.py)
+#define FS_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); st[k] += now_ - tprev; tprev = now_; } while (0)
+#else
+#define FS_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 struct Acc {
@@ -208,12 +214,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
     // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass, four
     // sphere loads in flight per lane.  Blacklisted / off-map candidates keep nothing: zero FI.
-    auto cull = [&](int c, int buf) {
+    // The pose record (R row-major, t) read here is handed to the scoring pass of the same candidate in registers.
+    auto cull = [&](int c, int buf, float *Rn, float *tn) {
         unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups, buf) + wave * a.n_groups;
         const bool dead = a.status && a.status[c] != FS_STATUS_OK;
         const float4 r0 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[0];
         const float4 r1 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[1];
         const float4 r2 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[2];
+        Rn[0] = r0.x; Rn[1] = r0.y; Rn[2] = r0.z; Rn[3] = r0.w; Rn[4] = r1.x; Rn[5] = r1.y; Rn[6] = r1.z; Rn[7] = r1.w;
+        Rn[8] = r2.x; tn[0] = r2.y; tn[1] = r2.z; tn[2] = r2.w;
         const float ax = r0.x, ay = r0.w, az = r1.z;               // the camera's +x axis in the world frame (R[0], R[3], R[6])
         const float t0 = r2.y, t1 = r2.z, t2 = r2.w;
         int tested = 0;
@@ -225,13 +234,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const float reach = a.max_dist_f + s.w;
                 keep = d2 <= reach * reach;
                 if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
-                    // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|)
-                    const float dist = sqrtf(d2);
-                    const float sb = s.w / dist;                           // < 1 here
-                    const float cb = sqrtf(fmaxf(0.0f, 1.0f - sb * sb));
-                    const float cab = a.cos_a * cb - a.sin_a * sb;          // cos(alpha + beta)
+                    // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
+                    // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one
+                    // hardware square root; the margin dwarfs its 1-ulp error)
+                    const float h = __builtin_amdgcn_sqrtf(d2 - s.w * s.w);
                     const float dot = dx * ax + dy * ay + dz * az;
-                    keep = dot >= dist * cab - 1.0e-4f * dist - 1.0e-4f;
+                    keep = dot >= a.cos_a * h - a.sin_a * s.w - (1.0e-4f * reach + 1.0e-4f);     // |d| <= reach here
                 }
             }
             return keep;
@@ -257,17 +265,33 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     };
 
     // ---- prologue: first candidate, factor table
-    if (tid == 0) { sh_next[0] = fetch(); sh_overflow[0] = 0; sh_overflow[1] = 0; sh_nvox[0] = 0; sh_nvox[1] = 0; }
+    // Work items are fetched two candidates ahead: the atomic's round trip (and the dependent list lookup) is issued by
+    // thread 0 at the top of an iteration and only consumed after that iteration's scoring loop.
+    if (tid == 0) {
+        const int first = fetch();
+        sh_next[0] = first; sh_next[1] = first >= 0 ? fetch() : -1;
+        sh_overflow[0] = 0; sh_overflow[1] = 0; sh_nvox[0] = 0; sh_nvox[1] = 0;
+    }
     for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
     __syncthreads();
     int cur = sh_next[0];
     int buf = 0;
-    if (cur >= 0) cull(cur, 0);
+    float Rn[9], tn[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rn[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tn[i] = 0.f;
+    if (cur >= 0) cull(cur, 0, Rn, tn);
     __syncthreads();
 
+#ifdef FS_FIM_STAMPS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     while (cur >= 0) {
         const int c = cur;
-        if (tid == 0) sh_next[buf ^ 1] = fetch();
+        int ahead = -1;
+        if (tid == 0 && sh_next[buf ^ 1] >= 0) ahead = fetch();    // the candidate after the next one; stored below
         int wg_tested = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) wg_tested += sh_wave_tested[buf][w];
@@ -294,15 +318,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        // ---- pose
+        // ---- pose (read by this candidate's cull)
         float R[9], t[3];
-        {
-            const float4 *p4 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c);
-            const float4 r0 = p4[0], r1 = p4[1], r2 = p4[2];
-            R[0] = r0.x; R[1] = r0.y; R[2] = r0.z; R[3] = r0.w; R[4] = r1.x; R[5] = r1.y; R[6] = r1.z; R[7] = r1.w;
-            R[8] = r2.x; t[0] = r2.y; t[1] = r2.z; t[2] = r2.w;
-        }
-        __syncthreads();                                           // table cleared, sh_next published
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = tn[i];
+        FS_STAMP(0);
+        __syncthreads();                                           // table cleared
+        FS_STAMP(1);
         const int nxt = sh_next[buf ^ 1];
         if (tid == 0) { sh_overflow[buf ^ 1] = 0; sh_nvox[buf ^ 1] = 0; }   // flags of the candidate after this one
         volatile int *v_overflow = &sh_overflow[buf];
@@ -381,6 +405,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 c1 = c2; x1 = x2; y1 = y2; z1 = z2;
             }
         }
+        FS_STAMP(2);
         if (skip_tier) qcount = 0;
         // flush the queue remainder
         if (qcount > 0) {
@@ -388,10 +413,13 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             score_visible(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
         }
         if (overflow) *v_overflow = 1;
+        FS_STAMP(3);
 
         // ---- the next candidate's cull fills the time this wave would otherwise wait for the slower ones
-        if (nxt >= 0) cull(nxt, buf ^ 1);
+        if (tid == 0) sh_next[buf] = ahead;                        // read by the next iteration after its first barrier
+        if (nxt >= 0) cull(nxt, buf ^ 1, Rn, tn);
 
+        FS_STAMP(4);
         // ---- 5. reduce: DPP within the wave, then across waves through LDS
         float vals[FS_NACC];
         vals[0] = acc.info;
@@ -407,7 +435,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #pragma unroll
             for (int i = 0; i < FS_NACC; ++i) sh_red[wave * FS_NACC + i] = vals[i];
         }
+        FS_STAMP(5);
         __syncthreads();
+        FS_STAMP(6);
         // cross-wave sums in fp64, one thread per quantity; the 6x6 assembly and log det run in
         // fs_fim_finish_kernel so that this kernel carries no private arrays
         const bool failed = sh_overflow[buf] != 0;
@@ -428,7 +458,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         }
         cur = nxt;
         buf ^= 1;
+        FS_STAMP(7);
     }
+#ifdef FS_FIM_STAMPS
+    if (lane == 0 && !GLOBAL_TABLE && fail_code == a.fail_code1) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&a.counters[16 + k], st[k]);
+        atomicAdd(&a.counters[24], 1ull);
+    }
+#endif
 }
 
 // tier 1: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
