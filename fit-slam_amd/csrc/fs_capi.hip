@@ -66,7 +66,7 @@ struct fs_ctx {
 
     // grid
     bool have_grid = false;
-    DevBuf<uint8_t> d_cells;
+    DevBuf<uint8_t> d_cells, d_bricks;    // dense row-major image and its 8x8x2-brick copy (FsGridDev)
     int32_t nx = 0, ny = 0, nz = 0;
     double origin[3] = {0, 0, 0};
     double res = 0.0;
@@ -124,6 +124,7 @@ struct fs_ctx {
     size_t sort_scratch_bytes = 0;
     DevBuf<int32_t> d_perm;
     bool opt_sort = true;
+    int opt_layout = 0;            // 0 auto, 1 row-major walk, 2 bricked walk
 
     // timing
     bool timing = false;
@@ -348,6 +349,30 @@ void pose_to_rt(const double pose7[7], float Rt[12])
     Rt[9] = (float)pose7[0]; Rt[10] = (float)pose7[1]; Rt[11] = (float)pose7[2];
 }
 
+// Which copy of the grid a ray kernel walks: the bricked walk costs ~2x the integer work per step and touches 2-4x
+// fewer cache lines; measured on C3 it loses 12 % at L = 40 cells and wins 10 % at L = 160.  "ray.layout" forces one.
+int use_bricks(const fs_ctx *c, double max_length_cells)
+{
+    if (c->opt_layout == 1) return 0;
+    if (c->opt_layout == 2) return 1;
+    return max_length_cells >= 96.0 ? 1 : 0;
+}
+
+FsGridDev grid_dev(const fs_ctx *c)
+{
+    return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res,
+                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3};
+}
+
+// every upload path ends here: the ray kernels read the bricked copy
+int retile_grid(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz)
+{
+    const size_t bytes = (size_t)((nx + 7) >> 3) * (size_t)((ny + 7) >> 3) * (size_t)((nz + 1) >> 1) * FS_BRICK_BYTES;
+    FS_HIP(c, c->d_bricks.ensure(bytes));
+    FS_HIP(c, fs_launch_retile(c->d_cells.p, c->d_bricks.p, nx, ny, nz, c->stream));
+    return FS_OK;
+}
+
 int check_scoring_state(fs_ctx *c, bool need_rays, bool need_fim)
 {
     if (need_rays && !c->have_ray) return fail(c, FS_E_STATE, "fs_set_ray_params has not been called");
@@ -360,10 +385,11 @@ int check_scoring_state(fs_ctx *c, bool need_rays, bool need_fim)
 int fill_ray_args(fs_ctx *c, FsRayArgs &a)
 {
     const fs_ray_params &p = c->rp;
-    a.grid = FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res};
+    a.grid = grid_dev(c);
     a.dir = c->d_dir.p;
     a.n_yaw = c->n_yaw; a.n_elev = c->n_elev; a.window = c->window;
     a.max_length = (unsigned int)(p.max_camera_depth / c->res);             // CostCalculator.cpp:28
+    a.bricked = use_bricks(c, (double)a.max_length);
     a.obst_min = p.obst_min; a.obst_max = p.obst_max; a.trace_min = p.trace_min; a.trace_max = p.trace_max;
     a.clamp = 1;
     // CostCalculator.cpp:47-48, getSizeInMeters = (size - 1 + 0.5) * resolution
@@ -480,7 +506,7 @@ void fs_ctx_destroy(fs_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release();
+    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_bricks.release();
     c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
     c->d_kf_check.release(); c->d_kf_tri.release(); c->d_kf_off.release(); c->d_kf_flagged.release(); c->d_kf_cells.release();
@@ -620,6 +646,10 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
     if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
     FS_HIP(c, c->d_cells.ensure((size_t)total));
     FS_HIP(c, hipMemcpyAsync(c->d_cells.p, cells, (size_t)total, hipMemcpyHostToDevice, c->stream));
+    {
+        const int rc = retile_grid(c, nx, ny, nz);
+        if (rc) return rc;
+    }
     FS_HIP(c, hipStreamSynchronize(c->stream));
     c->nx = nx; c->ny = ny; c->nz = nz;
     c->origin[0] = origin_xyz[0]; c->origin[1] = origin_xyz[1]; c->origin[2] = origin_xyz[2];
@@ -654,6 +684,10 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
         FS_HIP(c, hipStreamSynchronize(c->stream));
         d_xyz.release(); d_bc.release(); d_bad.release();
         if (bad) { c->have_grid = false; return fail(c, FS_E_INVALID, "a brick lies outside the grid"); }
+    }
+    {
+        const int rc = retile_grid(c, nx, ny, nz);
+        if (rc) return rc;
     }
     FS_HIP(c, hipStreamSynchronize(c->stream));
     c->nx = nx; c->ny = ny; c->nz = nz;
@@ -832,8 +866,9 @@ int fs_trace_segments(fs_ctx *c, int32_t n, const double *start_xyz, const doubl
     FS_HIP(c, hipMemcpyAsync(d_s.p, start_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     FS_HIP(c, hipMemcpyAsync(d_e.p, end_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
     FsSegArgs a{};
-    a.grid = FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res};
+    a.grid = grid_dev(c);
     a.n = n; a.start = d_s.p; a.end = d_e.p; a.max_length = max_length_cells;
+    a.bricked = use_bricks(c, max_length_cells);
     a.obst_min = obst_min; a.obst_max = obst_max; a.trace_min = trace_min; a.trace_max = trace_max;
     a.ok = d_ok.p; a.hit = d_hit.p; a.traced = d_tr.p; a.unknown = d_un.p; a.all = d_all.p;
     FS_HIP(c, fs_launch_segments(a, c->stream));
@@ -942,6 +977,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 2) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);

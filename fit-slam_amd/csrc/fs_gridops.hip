@@ -109,7 +109,38 @@ void fs_frontier_pair_kernel(int n, const float *lx, const float *ly, const floa
     if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// dense row-major grid -> 8 x 8 x 2 bricks (fs_internal.h): one thread moves the 8 cells of a brick row, which are
+// contiguous in both layouts
+__global__ void fs_retile_kernel(const uint8_t *__restrict__ cells, uint8_t *__restrict__ bricks, int nx, int ny, int nz)
+{
+    const uint32_t nx8 = (uint32_t)(nx + 7) >> 3, bx = nx8, by = (uint32_t)(ny + 7) >> 3;
+    const long long total = (long long)nx8 * ny * nz;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t x8 = (uint32_t)(i % nx8);
+        const long long r = i / nx8;
+        const uint32_t y = (uint32_t)(r % ny), z = (uint32_t)(r / ny);
+        const uint8_t *src = cells + ((size_t)z * ny + y) * nx + (size_t)x8 * 8;
+        uint8_t *dst = bricks + fs_brick_offset(bx, by, x8 * 8, y, z);
+        if ((nx & 7) == 0) {
+            *reinterpret_cast<unsigned long long *>(dst) = *reinterpret_cast<const unsigned long long *>(src);
+        } else {
+            const int n = min(8, nx - (int)x8 * 8);
+            for (int k = 0; k < n; ++k) dst[k] = src[k];
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t fs_launch_retile(const uint8_t *d_cells, uint8_t *d_bricks, int nx, int ny, int nz, hipStream_t s)
+{
+    const long long total = (long long)((nx + 7) >> 3) * ny * nz;
+    if (total <= 0) return hipSuccess;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(fs_retile_kernel, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0, s,
+                       d_cells, d_bricks, nx, ny, nz);
+    return hipGetLastError();
+}
 
 hipError_t fs_launch_frontier_pair(int n, const float *lx, const float *ly, const float *lz, int m, const float *d_Rt,
                                    const double *d_tri, float *d_out, hipStream_t s)

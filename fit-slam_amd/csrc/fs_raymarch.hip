@@ -40,7 +40,12 @@ __device__ __forceinline__ bool world_to_map(const FsGridDev &g, double wx, doub
 
 __device__ __forceinline__ int sign_ref(int x) { return x > 0 ? 1 : -1; }   // Helpers.hpp:113-116
 
-struct RayWalk {
+// Two interchangeable walks over the same cell sequence (selected per launch, FsRayArgs::bricked):
+//
+// WalkLinear — the reference's own formulation on the dense row-major image: a linear offset, constant strides per
+// axis, bresenham2D's body (DEP/src/Helpers.cpp:21-27) with a second minor axis.  Cheapest in ALU; rows only give
+// x-major rays any cache-line reuse.
+struct WalkLinear {
     uint32_t offset;
     uint32_t abs_da, abs_db, abs_dc;
     int err_b, err_c;
@@ -48,9 +53,22 @@ struct RayWalk {
     uint32_t end;            // min(max_length_steps, abs_da): loop visits, one more after the loop
 };
 
-__device__ __forceinline__ void walk_step(RayWalk &w)
+// WalkBricked — on the 8 x 8 x 2-brick copy, which has no constant strides: the walk keeps the cell coordinates and
+// applies the same body to every axis alike: an axis steps when its error term, advanced by |d_axis|, reaches
+// |d_major|.  The minor axes follow the reference's `error_b` exactly; for the major axis the term is advanced by
+// |d_major| itself and fires on every step — the unconditional `offset += offset_a`.  ~2x the integer work per
+// step, 2-4x fewer cache lines per ray: pays for long rays (measured cross-over between L = 40 and L = 160).
+struct WalkBricked {
+    int x, y, z;
+    int sgx, sgy, sgz;       // sign(dx) etc. with sign(0) = -1 (Helpers.hpp:113-116)
+    uint32_t adx, ady, adz;
+    uint32_t abs_da;         // max of the three
+    int ex, ey, ez;
+    uint32_t end;
+};
+
+__device__ __forceinline__ void walk_step(WalkLinear &w)
 {
-    // bresenham2D body, DEP/src/Helpers.cpp:21-27 (+ second minor axis)
     w.offset += (uint32_t)w.off_a;
     w.err_b += (int)w.abs_db;
     if ((uint32_t)w.err_b >= w.abs_da) { w.offset += (uint32_t)w.off_b; w.err_b -= (int)w.abs_da; }
@@ -58,22 +76,44 @@ __device__ __forceinline__ void walk_step(RayWalk &w)
     if ((uint32_t)w.err_c >= w.abs_da) { w.offset += (uint32_t)w.off_c; w.err_c -= (int)w.abs_da; }
 }
 
-// getTracedCells set-up, DEP/src/Helpers.cpp:32-94.
-__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, double sx, double sy, double sz,
-                                          double wx, double wy, double wz, RayWalk &w)
+__device__ __forceinline__ void walk_step(WalkBricked &w)
 {
-    const FsGridDev &g = a.grid;
-    uint32_t x1, y1, z1, x0, y0, z0;
-    if (!world_to_map(g, wx, wy, wz, x1, y1, z1) || !world_to_map(g, sx, sy, sz, x0, y0, z0)) return false;
-    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
+    w.ex += (int)w.adx;
+    if ((uint32_t)w.ex >= w.abs_da) { w.x += w.sgx; w.ex -= (int)w.abs_da; }
+    w.ey += (int)w.ady;
+    if ((uint32_t)w.ey >= w.abs_da) { w.y += w.sgy; w.ey -= (int)w.abs_da; }
+    w.ez += (int)w.adz;
+    if ((uint32_t)w.ez >= w.abs_da) { w.z += w.sgz; w.ez -= (int)w.abs_da; }
+}
+
+// The cell under the walk.  Both end points are on the map (worldToMap succeeded) and a Bresenham walk between two
+// cells never leaves their bounding box — each axis takes at most |d_axis| steps towards the end point — so every
+// visit, including the speculative ones (they stay within `visits`), is inside the grid.
+__device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkLinear &w) { return (int)g.cells[w.offset]; }
+__device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkBricked &w)
+{
+    return (int)g.bricks[fs_brick_offset((uint32_t)g.bx, (uint32_t)g.by, (uint32_t)w.x, (uint32_t)w.y, (uint32_t)w.z)];
+}
+
+// getTracedCells from the two map cells on (Helpers.cpp:46-94): `(unsigned)(scale * abs_da)` visits
+__device__ __forceinline__ uint32_t walk_visits(int dx, int dy, int dz, uint32_t abs_da, double max_length)
+{
     const long long d2 = (long long)dx * dx + (long long)dy * dy + (long long)dz * dz;
     const double dist = sqrt((double)d2);          // == std::hypot(dx,dy) when dz == 0 (both correctly rounded)
+    const double q = max_length / dist;
+    const double scale = (dist == 0.0) ? 1.0 : ((q < 1.0) ? q : 1.0);       // std::min(1.0, max_length / dist)
+    const uint32_t max_steps = (uint32_t)(scale * (double)abs_da);
+    return max_steps < abs_da ? max_steps : abs_da;
+}
+
+__device__ __forceinline__ void walk_init(WalkLinear &w, const FsGridDev &g, uint32_t x0, uint32_t y0, uint32_t z0,
+                                          uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
+{
+    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
     const uint32_t nx = (uint32_t)g.nx, ny = (uint32_t)g.ny;
     w.offset = (z0 * ny + y0) * nx + x0;
     const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
     const int odx = sign_ref(dx), ody = sign_ref(dy) * (int)nx, odz = sign_ref(dz) * (int)(nx * ny);
-    const double q = (double)a.max_length / dist;
-    const double scale = (dist == 0.0) ? 1.0 : ((q < 1.0) ? q : 1.0);       // std::min(1.0, max_length / dist)
     if (adx >= ady && adx >= adz) {
         w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
     } else if (ady >= adz) {
@@ -82,17 +122,38 @@ __device__ __forceinline__ bool ray_setup(const FsRayArgs &a, double sx, double 
         w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody;
     }
     w.err_b = w.err_c = (int)(w.abs_da / 2);
-    const uint32_t max_steps = (uint32_t)(scale * (double)w.abs_da);
-    w.end = max_steps < w.abs_da ? max_steps : w.abs_da;
+    w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
+}
+
+__device__ __forceinline__ void walk_init(WalkBricked &w, const FsGridDev &, uint32_t x0, uint32_t y0, uint32_t z0,
+                                          uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
+{
+    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
+    w.x = (int)x0; w.y = (int)y0; w.z = (int)z0;
+    w.adx = (uint32_t)abs(dx); w.ady = (uint32_t)abs(dy); w.adz = (uint32_t)abs(dz);
+    w.sgx = sign_ref(dx); w.sgy = sign_ref(dy); w.sgz = sign_ref(dz);
+    w.abs_da = w.adx >= w.ady ? (w.adx >= w.adz ? w.adx : w.adz) : (w.ady >= w.adz ? w.ady : w.adz);
+    w.ex = w.ey = w.ez = (int)(w.abs_da / 2);
+    w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
+}
+
+// The start cell is the same for every ray of a fan: its worldToMap (three fp64 divisions) is done once per candidate;
+// a start point off the map fails every ray, like the reference's `||` of the two conversions (Helpers.cpp:40).
+template <typename Walk>
+__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, bool start_ok, uint32_t x0, uint32_t y0, uint32_t z0,
+                                          double wx, double wy, double wz, Walk &w)
+{
+    uint32_t x1, y1, z1;
+    if (!world_to_map(a.grid, wx, wy, wz, x1, y1, z1) || !start_ok) return false;
+    walk_init(w, a.grid, x0, y0, z0, x1, y1, z1, (double)a.max_length);
     return true;
 }
 
 // RayTracedCells over the walk: number of cells in [trace_min,trace_max] seen before the first
 // cell in [obst_min,obst_max]  (= cells_.size(), DEP/src/CostCalculator.cpp:57-58).
-__device__ __forceinline__ int ray_march(const FsRayArgs &a, RayWalk w)
+template <typename Walk>
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
 {
-    const uint8_t *__restrict__ cells = a.grid.cells;
-    const uint32_t total = (uint32_t)a.grid.nx * (uint32_t)a.grid.ny * (uint32_t)a.grid.nz;
     const int omin = a.obst_min, omax = a.obst_max, tmin = a.trace_min, tmax = a.trace_max;
     int count = 0;
     uint32_t visits = w.end + 1;          // loop visits + the one after the loop (Helpers.cpp:29)
@@ -105,7 +166,7 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, RayWalk w)
         for (int u = 0; u < FS_RAY_UNROLL; ++u) {
             c[u] = -1;
             if ((uint32_t)u < nb) {
-                c[u] = (w.offset < total) ? (int)cells[w.offset] : 256;   // 256: never traced, never an obstacle
+                c[u] = walk_cell(a.grid, w);
                 walk_step(w);
             }
         }
@@ -123,6 +184,7 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, RayWalk w)
     return count;
 }
 
+template <typename Walk>
 __global__ __launch_bounds__(FS_RAY_WAVES * 64)
 void fs_raymarch_kernel(const FsRayArgs a)
 {
@@ -150,6 +212,8 @@ void fs_raymarch_kernel(const FsRayArgs a)
         sx = a.goal[3 * c]; sy = a.goal[3 * c + 1]; sz = a.goal[3 * c + 2];
     }
     bool fail = false;
+    uint32_t sxm = 0, sym = 0, szm = 0;
+    const bool start_ok = active && world_to_map(a.grid, sx, sy, sz, sxm, sym, szm);
     if (active && !black) {
         for (int r = lane; r < n_rays; r += 64) {
             const int i = r % a.n_yaw;
@@ -162,9 +226,9 @@ void fs_raymarch_kernel(const FsRayArgs a)
                 wy = std_max(a.lo_y, std_min(a.hi_y, wy));
                 wz = std_max(a.lo_z, std_min(a.hi_z, wz));
             }
-            RayWalk w;
+            Walk w;
             int count = 0;
-            if (ray_setup(a, sx, sy, sz, wx, wy, wz, w)) count = ray_march(a, w);
+            if (ray_setup(a, start_ok, sxm, sym, szm, wx, wy, wz, w)) count = ray_march(a, w);
             else fail = true;
             if (count) atomicAdd(&ysum[i], count);
             if (a.ray_counts) a.ray_counts[(size_t)c * n_rays + r] = count;
@@ -186,8 +250,6 @@ void fs_raymarch_kernel(const FsRayArgs a)
     }
 
     // footprint disc, DEP/src/Helpers.cpp:135-155 in the candidate's z slice; off-grid cells are not lethal
-    uint32_t sxm = 0, sym = 0, szm = 0;
-    world_to_map(a.grid, sx, sy, sz, sxm, sym, szm);
     const int ri = (int)a.footprint_radius;
     const int side = 2 * ri + 1;
     bool lethal = false;
@@ -196,7 +258,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
         if ((double)(dx * dx + dy * dy) <= a.footprint_radius * a.footprint_radius) {
             const uint32_t x = sxm + (uint32_t)dx, y = sym + (uint32_t)dy;
             if (x < (uint32_t)a.grid.nx && y < (uint32_t)a.grid.ny) {
-                if (a.grid.cells[((size_t)szm * a.grid.ny + y) * a.grid.nx + x] == 254) lethal = true;
+                if (a.grid.bricks[fs_brick_offset((uint32_t)a.grid.bx, (uint32_t)a.grid.by, x, y, szm)] == 254) lethal = true;
             }
         }
     }
@@ -236,6 +298,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
 // One lane per segment: getTracedCells(sx, sy, wx, wy, visitor, max_length, costmap) for arbitrary end points
 // (DEP/src/Helpers.cpp:32-96) with every RayTracedCells accessor (Helpers.hpp:83-101).  Unlike the arrival
 // fan the walk never stops early: unknown_cells_ and all_cells_count_ keep counting behind an obstacle.
+template <typename Walk>
 __global__ void fs_segments_kernel(const FsSegArgs s)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,26 +313,11 @@ __global__ void fs_segments_kernel(const FsSegArgs s)
     bool hit = false, ok = false;
     if (world_to_map(g, wx, wy, wz, x1, y1, z1) && world_to_map(g, sx, sy, sz, x0, y0, z0)) {
         ok = true;
-        const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
-        const long long d2 = (long long)dx * dx + (long long)dy * dy + (long long)dz * dz;
-        const double dist = sqrt((double)d2);
-        const uint32_t nx = (uint32_t)g.nx, ny = (uint32_t)g.ny;
-        RayWalk w;
-        w.offset = (z0 * ny + y0) * nx + x0;
-        const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
-        const int odx = sign_ref(dx), ody = sign_ref(dy) * (int)nx, odz = sign_ref(dz) * (int)(nx * ny);
-        const double q = s.max_length / dist;
-        const double scale = (dist == 0.0) ? 1.0 : ((q < 1.0) ? q : 1.0);
-        if (adx >= ady && adx >= adz) { w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz; }
-        else if (ady >= adz) { w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz; }
-        else { w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody; }
-        w.err_b = w.err_c = (int)(w.abs_da / 2);
-        const uint32_t max_steps = (uint32_t)(scale * (double)w.abs_da);
-        const uint32_t end = max_steps < w.abs_da ? max_steps : w.abs_da;
-        const uint32_t total = nx * ny * (uint32_t)g.nz;
-        for (uint32_t v = 0; v <= end; ++v) {
-            if (w.offset < total) {
-                const int c = (int)g.cells[w.offset];
+        Walk w;
+        walk_init(w, g, x0, y0, z0, x1, y1, z1, s.max_length);
+        for (uint32_t v = 0; v <= w.end; ++v) {
+            const int c = walk_cell(g, w);
+            {
                 ++all;                                                        // Helpers.hpp:62
                 if (c <= s.trace_max && c >= s.trace_min && !hit) ++traced;   // :64-67
                 if (c >= s.obst_min && c <= s.obst_max) hit = true;           // :68-71
@@ -320,14 +368,16 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
     int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
     if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
-    hipLaunchKernelGGL(fs_raymarch_kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    if (a.bricked) hipLaunchKernelGGL(fs_raymarch_kernel<WalkBricked>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    else hipLaunchKernelGGL(fs_raymarch_kernel<WalkLinear>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t fs_launch_segments(const FsSegArgs &a, hipStream_t s)
 {
     if (a.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fs_segments_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+    if (a.bricked) hipLaunchKernelGGL(fs_segments_kernel<WalkBricked>, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(fs_segments_kernel<WalkLinear>, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -112,7 +112,10 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
 
 /* Tuning / diagnostic knobs (no reference counterpart).  Keys: "fim.cull" (default 1): per-chunk
  * bounding-sphere culling of the landmark cloud; 0 tests every landmark (brute force; identical results).
- * "ray.sort" (default 1): ray-march candidates in Morton order of their goal cell (lists of >= 2048). */
+ * "ray.sort" (default 1): ray-march candidates in Morton order of their goal cell (lists of >= 2048).
+ * "ray.layout" (default 0): which copy of the grid the ray walks read — 0 picks by ray length (row-major image below
+ * 96 cells, 8x8x2-brick copy from there on), 1 / 2 force the row-major / bricked walk (identical results).
+ * "fim.bits1", "fim.skip32": development knobs of the hash-table tiers. */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
 /* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
  * 4/5/6 = candidates re-scored by the second / third hash-table tier / unresolved (always 0). */

@@ -416,3 +416,42 @@ def test_information_for_pose_hbm_table_pass(fs, oracle, scorer):
     np.testing.assert_array_equal(got["n_cells"], want["n_cells"])
     np.testing.assert_array_equal(got["n_points"], want["n_points"])
     np.testing.assert_allclose(got["information"], want["info_f64"], rtol=1e-4, atol=1e-6)
+
+
+def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
+    """The row-major walk and the walk over the 8x8x2-brick copy visit the same cells: bit-exact against the oracle and
+    against each other, for short and long rays, odd grid sizes (partial bricks) and arbitrary segments."""
+    rng = np.random.default_rng(77)
+    try:
+        for name, depth_cells in (("C1_2D", 40), ("C1", 40), ("C2", 160)):
+            w = fs.synth.make_workload(name, n_cand=400)
+            w.max_camera_depth = depth_cells * w.resolution
+            G, P = _oracle_grid_params(oracle, w)
+            _setup_scorer(scorer, w)
+            mx_o = oracle.max_arrival_information(G, P)
+            want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], n_threads=8)
+            for layout in (1, 2, 0):
+                scorer.set_option("ray.layout", layout)
+                assert scorer.max_arrival() == mx_o
+                _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
+        # odd sizes: nx, ny not multiples of 8, nz odd
+        cells = rng.choice(np.array([0, 0, 0, 255, 255, 254, 250], np.uint8), size=(5, 37, 43))
+        origin = (-1.0, -0.9, -0.1)
+        G = oracle.Grid(cells, origin=origin, resolution=0.05)
+        scorer.upload_grid(cells, origin, 0.05)
+        lo = np.array(origin); hi = lo + np.array([43, 37, 5]) * 0.05
+        a = rng.uniform(lo - 0.05, hi + 0.05, size=(500, 3)); b = rng.uniform(lo - 0.05, hi + 0.05, size=(500, 3))
+        res = {}
+        for layout in (1, 2):
+            scorer.set_option("ray.layout", layout)
+            res[layout] = scorer.trace_segments(a, b, 200, obst=(254, 254), trace=(0, 255))
+        for k in ("ok", "traced", "hit", "unknown", "all"):
+            np.testing.assert_array_equal(res[1][k], res[2][k])
+        for i in range(0, 500, 5):
+            r = oracle.trace_ray(G, a[i], b[i], 200, obst=(254, 254), trace=(0, 255), faithful=True)
+            assert bool(res[2]["ok"][i]) == r["ok"]
+            if r["ok"]:
+                assert (res[2]["traced"][i], bool(res[2]["hit"][i]), res[2]["unknown"][i], res[2]["all"][i]) == \
+                    (r["traced"], r["hit"], r["unknown"], r["all"]), i
+    finally:
+        scorer.set_option("ray.layout", 0)
