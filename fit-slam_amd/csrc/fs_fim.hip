@@ -40,6 +40,9 @@
 #define FS_STAMP(k) do { } while (0)
 #endif
 
+#define FS_T1_THREADS 512
+#define FS_T2_THREADS 1024
+
 namespace {
 
 struct Acc {
@@ -56,8 +59,11 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
 }
 
 // Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch).
-// Written as predicated straight-line code: the scalar unit, not the vector ALU, limited the branchy version.
+// Written as predicated straight-line code (selects, no per-lane branches): the scalar unit, not the vector ALU,
+// limited the branchy version.  TABLE_FULL (no NaN holes inside the table box: every generated table) removes the
+// only dependence of the hash update on the gathered table value, so that load is first waited for at the very end.
 // Returns true when this landmark opened a new voxel entry.
+template <bool TABLE_FULL>
 __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
                                               bool active, float px, float py, float pz, Acc &acc, bool &overflow)
 {
@@ -78,13 +84,13 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     }
     jx -= a.jx0; jy -= a.jy0; jz -= a.jz0;
     const bool in_table = active && (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
-    const uint32_t key = in_table ? ((uint32_t)jx * (uint32_t)a.ty + (uint32_t)jy) * (uint32_t)a.tz + (uint32_t)jz : 0u;
+    // table extents are < 2^11 each and the cell count < 2^21 (FS_MAX_TABLE_CELLS): 24-bit multiplies are exact
+    const uint32_t key = in_table ? __umul24(__umul24((uint32_t)jx, (uint32_t)a.ty) + (uint32_t)jy, (uint32_t)a.tz) + (uint32_t)jz : 0u;
     // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
     const float info_t = a.table[key];
 
-    // a table without holes (every generated table) lets the hash update start without waiting for the gathered value
     bool valid = in_table;
-    if (!a.table_full) valid = valid && (info_t == info_t);
+    if (!TABLE_FULL) valid = valid && (info_t == info_t);
     // ---- the voxel's hash bucket (the reference's pointCount bookkeeping, :296-304).  The table is organised in
     // buckets of four slots read with ONE 16-byte LDS load: at the load factors used (< 0.5) a bucket almost never
     // fills up, so nearly every landmark resolves with one read plus one atomic instead of walking a probe chain.
@@ -116,25 +122,30 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
             if (!done) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
         }
         const uint32_t w0 = bk.x, w1 = bk.y, w2 = bk.z, w3 = bk.w;
-        const int jm = ((w0 & ~FS_SLOT_CNT_MASK) == tag) ? 0 : ((w1 & ~FS_SLOT_CNT_MASK) == tag) ? 1
-                     : ((w2 & ~FS_SLOT_CNT_MASK) == tag) ? 2 : ((w3 & ~FS_SLOT_CNT_MASK) == tag) ? 3 : -1;
-        const int je = (w0 == 0u) ? 0 : (w1 == 0u) ? 1 : (w2 == 0u) ? 2 : (w3 == 0u) ? 3 : -1;   // slots fill in order
-        const bool has_match = jm >= 0;
-        const bool can_insert = !has_match && je >= 0;
-        uint32_t *slot = table + (hb << 2) + (has_match ? jm : (je >= 0 ? je : 0));
+        // a slot holds my voxel iff it agrees with the tag above the count bits (an empty slot never does: tag >= 2^11)
+        const bool m0 = (w0 ^ tag) <= FS_SLOT_CNT_MASK, m1 = (w1 ^ tag) <= FS_SLOT_CNT_MASK;
+        const bool m2 = (w2 ^ tag) <= FS_SLOT_CNT_MASK, m3 = (w3 ^ tag) <= FS_SLOT_CNT_MASK;
+        const bool has_match = m0 || m1 || m2 || m3;
+        const uint32_t cur_match = m0 ? w0 : (m1 ? w1 : (m2 ? w2 : w3));
+        const uint32_t jm = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u));
+        // slots fill in order: the first empty one is the number of occupied ones
+        const uint32_t used = (w0 != 0u ? 1u : 0u) + (w1 != 0u ? 1u : 0u) + (w2 != 0u ? 1u : 0u) + (w3 != 0u ? 1u : 0u);
+        const bool can_insert = !has_match && used < 4u;
+        uint32_t *slot = table + (hb << 2) + (has_match ? jm : (used < 4u ? used : 0u));
         uint32_t prev = 0xffffffffu;
         if (!done && can_insert) prev = atomicCAS(slot, 0u, tag | 1u);    // 0: this lane created the entry
         const bool won = !done && can_insert && prev == 0u;
-        const bool late = !done && can_insert && prev != 0u && (prev & ~FS_SLOT_CNT_MASK) == tag;   // my voxel just arrived there
+        const bool late = !done && can_insert && prev != 0u && (prev ^ tag) <= FS_SLOT_CNT_MASK;   // my voxel just arrived there
         const bool do_add = !done && (has_match || late);
-        const uint32_t cur = has_match ? (jm == 0 ? w0 : jm == 1 ? w1 : jm == 2 ? w2 : w3) : prev;
+        const uint32_t cur = has_match ? cur_match : prev;
         const bool sat = do_add && (cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT;                      // factor is 0.0f out there anyway
         uint32_t old = 0u;
         if (do_add && !sat) old = atomicAdd(slot, 1u);
-        if (won) { rank = 1u; is_new = true; }
-        if (do_add) rank = sat ? FS_SLOT_CNT_SAT + 1u : (old & FS_SLOT_CNT_MASK) + 1u;
-        const bool full = !done && !has_match && je < 0;                  // bucket holds four other voxels: next bucket
-        if (full) hb = (hb + 1u) & bmask;
+        const uint32_t add_rank = sat ? FS_SLOT_CNT_SAT + 1u : (old & FS_SLOT_CNT_MASK) + 1u;
+        rank = won ? 1u : (do_add ? add_rank : rank);
+        is_new = is_new || won;
+        const bool full = !done && !has_match && used >= 4u;              // bucket holds four other voxels: next bucket
+        hb = full ? ((hb + 1u) & bmask) : hb;
         done = done || won || do_add;                                     // a lost CAS against another voxel re-reads the bucket
     }
     if (!done) { overflow = true; rank = 0u; }
@@ -189,7 +200,7 @@ struct FimWork {
 // finished its share of candidate i culls the chunks of candidate i+1 before it joins the reduction barrier, so the
 // latency of the sphere loads and the imbalance between waves overlap instead of adding up.  Two barriers per
 // candidate: after the table clear and after the reduction.
-template <int THREADS, bool GLOBAL_TABLE>
+template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL>
 __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits,
                                            const uint32_t fail_code)
 {
@@ -391,7 +402,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                         qcount -= 64;                              // take the newest 64: the remainder stays in place
                         const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
                         // ---- 4. score
-                        const bool opened = score_visible(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
+                        const bool opened = score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
                         const unsigned long long om = __ballot(opened);
                         if (!GLOBAL_TABLE && om != 0ull) {
                             int total = 0;
@@ -410,7 +421,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // flush the queue remainder
         if (qcount > 0) {
             const bool have = lane < qcount;
-            score_visible(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
+            score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
         }
         if (overflow) *v_overflow = 1;
         FS_STAMP(3);
@@ -469,34 +480,34 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 }
 
 // tier 1: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
-template <int THREADS>
+template <int THREADS, bool TABLE_FULL>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
-    fim_worker<THREADS, false>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits, a.fail_code1);
+    fim_worker<THREADS, false, TABLE_FULL>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits, a.fail_code1);
 }
 
 // tier 2: candidates tier 1 appended to its work list, with a larger LDS table
-template <int THREADS>
+template <int THREADS, bool TABLE_FULL>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_tier2_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.flagged, 0, (int)a.counters[1], a.counters + 7};
-    fim_worker<THREADS, false>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2, 2u);
+    fim_worker<THREADS, false, TABLE_FULL>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2, 2u);
 }
 
 // tier 3: candidates on the second work list; table in HBM with 2x the landmark count of slots and unbounded probing
-template <int THREADS>
+template <int THREADS, bool TABLE_FULL>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_tier3_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.flagged + a.n, 0, (int)a.counters[2], a.counters + 9};
     uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
-    fim_worker<THREADS, true>(a, work, fs_fim_lds, table, a.ghash_bits, 3u);
+    fim_worker<THREADS, true, TABLE_FULL>(a, work, fs_fim_lds, table, a.ghash_bits, 3u);
 }
 
 // One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
@@ -602,8 +613,6 @@ hipError_t allow_lds(K kernel, size_t bytes)
 
 }  // namespace
 
-#define FS_T1_THREADS 512
-#define FS_T2_THREADS 1024
 
 size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks)
 {
@@ -611,36 +620,57 @@ size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks)
     return lds_bytes<FS_T2_THREADS>(hash_bits2, false, n_chunks, &groups) + 2048;   // + the worker's static arrays, rounded up
 }
 
+namespace {
+
+template <bool TABLE_FULL>
+hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
+{
+    const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
+    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL>;
+    hipError_t e = allow_lds(kernel, lds);
+    if (e != hipSuccess) return e;
+    static int resident = 0;                                   // same kernel, same LDS budget class: query once
+    static size_t resident_lds = 0;
+    if (resident == 0 || resident_lds != lds) { resident = resident_blocks(kernel, FS_T1_THREADS, lds); resident_lds = lds; }
+    hipLaunchKernelGGL(kernel, dim3(a.cand_count < resident ? a.cand_count : resident), dim3(FS_T1_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
+template <bool TABLE_FULL>
+hipError_t launch_overflow(FsFimArgs &a, int pool, hipStream_t s)
+{
+    if (a.hash_bits2 > a.hash_bits) {
+        const size_t lds2 = lds_bytes<FS_T2_THREADS>(a.hash_bits2, false, a.n_chunks, &a.n_groups);
+        auto kernel2 = fs_fim_tier2_kernel<FS_T2_THREADS, TABLE_FULL>;
+        hipError_t e = allow_lds(kernel2, lds2);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kernel2, dim3(a.n < 256 ? a.n : 256), dim3(FS_T2_THREADS), lds2, s, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const int blocks = a.n < pool ? a.n : pool;
+    const size_t lds3 = lds_bytes<FS_T2_THREADS>(0, true, a.n_chunks, &a.n_groups);
+    auto kernel3 = fs_fim_tier3_kernel<FS_T2_THREADS, TABLE_FULL>;
+    hipError_t e = allow_lds(kernel3, lds3);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel3, dim3(blocks), dim3(FS_T2_THREADS), lds3, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
 hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
     if (a0.n <= 0 || a0.cand_count <= 0) return hipSuccess;
     FsFimArgs a = a0;
-    const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
-    hipError_t e = allow_lds(fs_fim_kernel<FS_T1_THREADS>, lds);
-    if (e != hipSuccess) return e;
-    static int resident = 0;                                   // same kernel, same LDS budget class: query once
-    static size_t resident_lds = 0;
-    if (resident == 0 || resident_lds != lds) { resident = resident_blocks(fs_fim_kernel<FS_T1_THREADS>, FS_T1_THREADS, lds); resident_lds = lds; }
-    hipLaunchKernelGGL(fs_fim_kernel<FS_T1_THREADS>, dim3(a.cand_count < resident ? a.cand_count : resident), dim3(FS_T1_THREADS), lds, s, a);
-    return hipGetLastError();
+    return a.table_full ? launch_tier1<true>(a, s) : launch_tier1<false>(a, s);
 }
 
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a0, int pool, hipStream_t s)
 {
     if (a0.n <= 0) return hipSuccess;
     FsFimArgs a = a0;
-    if (a.hash_bits2 > a.hash_bits) {
-        const size_t lds2 = lds_bytes<FS_T2_THREADS>(a.hash_bits2, false, a.n_chunks, &a.n_groups);
-        hipError_t e = allow_lds(fs_fim_tier2_kernel<FS_T2_THREADS>, lds2);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fs_fim_tier2_kernel<FS_T2_THREADS>, dim3(a.n < 256 ? a.n : 256), dim3(FS_T2_THREADS), lds2, s, a);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    const int blocks = a.n < pool ? a.n : pool;
-    const size_t lds3 = lds_bytes<FS_T2_THREADS>(0, true, a.n_chunks, &a.n_groups);
-    hipLaunchKernelGGL(fs_fim_tier3_kernel<FS_T2_THREADS>, dim3(blocks), dim3(FS_T2_THREADS), lds3, s, a);
-    return hipGetLastError();
+    return a.table_full ? launch_overflow<true>(a, pool, s) : launch_overflow<false>(a, pool, s);
 }
 
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s)
