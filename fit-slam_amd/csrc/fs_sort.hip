@@ -44,8 +44,14 @@ void fs_sortscan_kernel(uint32_t *hist, uint32_t *cursor)
     __shared__ uint32_t wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t v[PER], sum = 0;
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist + tid * PER);   // one 128-byte line per thread
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { v[k] = hist[tid * PER + k]; hist[tid * PER + k] = 0u; sum += v[k]; }
+    for (int k = 0; k < PER / 4; ++k) {
+        const uint4 q = h4[k];
+        h4[k] = make_uint4(0u, 0u, 0u, 0u);
+        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        sum += (q.x + q.y) + (q.z + q.w);
+    }
     uint32_t incl = sum;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(incl, d);
@@ -56,8 +62,16 @@ void fs_sortscan_kernel(uint32_t *hist, uint32_t *cursor)
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wave_tot[w];
     uint32_t run = base + incl - sum;
+    uint4 *c4 = reinterpret_cast<uint4 *>(cursor + tid * PER);
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { cursor[tid * PER + k] = run; run += v[k]; }
+    for (int k = 0; k < PER / 4; ++k) {
+        uint4 q;
+        q.x = run; run += v[4 * k];
+        q.y = run; run += v[4 * k + 1];
+        q.z = run; run += v[4 * k + 2];
+        q.w = run; run += v[4 * k + 3];
+        c4[k] = q;
+    }
 }
 
 __global__ void fs_sortscatter_kernel(int32_t n, const uint32_t *keys, uint32_t *cursor, int32_t *perm)

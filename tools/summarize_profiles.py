@@ -1,6 +1,6 @@
 """Turns the rocprofv3 outputs under gpurun_out/ (suffix given as argv[1], e.g. r1e) into the committed
 summaries under profiles/: kernel stats, per-dispatch PMC rows of our kernels, pmc_traffic.json."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 tag = sys.argv[1]
 dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01"
 name = sys.argv[3] if len(sys.argv) > 3 else "c3_final"
@@ -15,7 +15,7 @@ for kind in ("fetch", "write", "tcc"):
             w.writeheader(); w.writerows(rows)
         d = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
-            d[r["Kernel_Name"].split("::")[-1].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            d[re.search(r"fs_\w+(<\d+)?", r["Kernel_Name"]).group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in d.items():
             for c, vals in v.items():
                 vals = [x for x in vals if x > 0][-3:] or [0]
@@ -24,7 +24,12 @@ for f in glob.glob(f"gpurun_out/prof_c3_{tag}/runc/*_kernel_stats.csv"):
     shutil.copy(f, f"{dst}/{name}_kernel_stats.csv")
 if os.path.exists(f"gpurun_out/bench_c3_{tag}.json"):
     shutil.copy(f"gpurun_out/bench_c3_{tag}.json", f"{dst}/{name}_bench.json")
-fim = res.get("fs_fim_kernel<512>", {}); ray = res.get("fs_raymarch_kernel", {})
+def pick(prefix):
+    for k, v in res.items():
+        if k.startswith(prefix):
+            return v
+    return {}
+fim = pick("fs_fim_kernel<512"); ray = pick("fs_raymarch_kernel")
 hit = lambda v: v.get("TCC_HIT_sum", 0) / max(1.0, v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0))
 out = {"workload": "C3",
        "source": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum (separate passes) --kernel-trace -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-parity ({tag})",
