@@ -107,7 +107,7 @@ struct fs_ctx {
     // hash tables
     DevBuf<uint32_t> d_gtable;
     int ghash_bits = 0;
-    static constexpr int kPool = 128;
+    static constexpr int kPool = 256;     // tier 3: one 1024-thread workgroup per CU
 
     // per-candidate scratch
     DevBuf<double> d_goal, d_yaw, d_len, d_head, d_cost, d_au, d_du, d_sums;
@@ -440,7 +440,7 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     while (bits < c->opt_bits1 && (1 << bits) < 2 * c->m) ++bits;
     a.hash_bits = bits;
     a.hash_bits2 = ((1 << bits) < 2 * c->m) ? 15 : bits;
-    // very large clouds: the tier's double-buffered chunk masks no longer fit next to its 128-KiB table -> HBM tier directly
+    // very large clouds: the tier's chunk masks no longer fit next to its 128-KiB table -> HBM tier directly
     if (a.hash_bits2 > bits && fs_fim_tier2_lds_bytes(a.hash_bits2, c->n_chunks) > 160 * 1024) a.hash_bits2 = bits;
     a.fail_code1 = (a.hash_bits2 > a.hash_bits) ? 1u : 2u;
     a.skip32 = c->opt_skip32;
@@ -888,7 +888,7 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
 {
     if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    // chunk masks live in LDS (two buffers of one bit per chunk and wave pass) next to the 64-KiB tier-1 table
+    // chunk masks live in LDS (one bit per chunk) next to the 64-KiB tier-1 table
     if (m > 2000000) return fail(c, FS_E_INVALID, "at most 2,000,000 landmarks per context");
     // Morton order (10 bits per axis inside the cloud's bounding box) so that 64 consecutive landmarks
     // are spatial neighbours; non-finite points sort last.

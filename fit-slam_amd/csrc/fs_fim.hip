@@ -173,16 +173,17 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
     return v;
 }
 
-// dynamic-LDS carve-up of one workgroup: [per-wave compaction queues][factor copy][2 x chunk masks][hash table]
+// dynamic-LDS carve-up of one workgroup: [per-wave compaction queues][factor copy][chunk masks][hash table]
 template <int THREADS>
 struct Lds {
     static constexpr int WAVES = THREADS / 64;
     static constexpr size_t fixed_words = (size_t)WAVES * 3 * FS_QCAP + FS_FACTOR_N;
-    // two mask buffers (the next candidate is culled while the current one is still being scored)
-    static __host__ __device__ size_t mask_words(int n_groups) { const size_t w = 4 * (size_t)WAVES * n_groups; return w + (w & 2); }
-    static __device__ __forceinline__ unsigned long long *masks(uint32_t *base, int n_groups, int buf)
+    // One mask region per wave.  A wave culls the next candidate only after it has finished walking its own masks of
+    // the current one, and no wave ever reads another wave's masks: one buffer is enough for the pipelined loop.
+    static __host__ __device__ size_t mask_words(int n_groups) { const size_t w = 2 * (size_t)WAVES * n_groups; return w + (w & 2); }
+    static __device__ __forceinline__ unsigned long long *masks(uint32_t *base, int n_groups)
     {
-        return reinterpret_cast<unsigned long long *>(base + fixed_words) + (size_t)buf * WAVES * n_groups;
+        return reinterpret_cast<unsigned long long *>(base + fixed_words);
     }
     static __device__ __forceinline__ float *factor(uint32_t *base) { return reinterpret_cast<float *>(base) + WAVES * 3 * FS_QCAP; }
     static __device__ __forceinline__ float *queue(uint32_t *base, int wave) { return reinterpret_cast<float *>(base) + wave * (3 * FS_QCAP); }
@@ -227,7 +228,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // sphere loads in flight per lane.  Blacklisted / off-map candidates keep nothing: zero FI.
     // The pose record (R row-major, t) read here is handed to the scoring pass of the same candidate in registers.
     auto cull = [&](int c, int buf, float *Rn, float *tn) {
-        unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups, buf) + wave * a.n_groups;
+        unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
         const bool dead = a.status && a.status[c] != FS_STATUS_OK;
         const float4 r0 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[0];
         const float4 r1 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[1];
@@ -243,7 +244,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;   // s.w carries a safety margin: conservative
                 const float d2 = dx * dx + dy * dy + dz * dz;
                 const float reach = a.max_dist_f + s.w;
-                keep = d2 <= reach * reach;
+                keep = reach >= 0.0f && d2 <= reach * reach;         // empty chunks carry a hugely negative radius
                 if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
                     // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
                     // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one
@@ -352,7 +353,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc.s[i] = 0.f;
         int qcount = 0;                                            // wave-uniform
-        const unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups, buf) + wave * a.n_groups;
+        const unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
 
         // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
         // next chunks' landmarks prefetched into registers while the current one is processed.

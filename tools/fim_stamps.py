@@ -3,7 +3,7 @@ import importlib, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 fs = importlib.import_module("fit-slam_amd")
-w = fs.synth.make_workload("C3")
+w = fs.synth.make_workload(sys.argv[1] if len(sys.argv) > 1 else "C3")
 sc = fs.FrontierScorer(0)
 sc.set_ray_params(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
                   robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
