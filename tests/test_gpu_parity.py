@@ -455,3 +455,37 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
                     (r["traced"], r["hit"], r["unknown"], r["all"]), i
     finally:
         scorer.set_option("ray.layout", 0)
+
+
+def test_fim_table_with_holes(fs, oracle, scorer, ref_table):
+    """A loaded table may miss keys (the reference's lookup returns NaN and the landmark is skipped, no voxel is
+    counted: FisherInfoManager.cpp:90-94,287-324).  Exercises the kernels compiled for tables with holes."""
+    rng = np.random.default_rng(17)
+    rec = ref_table.records
+    keep = rng.random(rec.shape[0]) < 0.7
+    keep[-1] = True                                           # the trailing (0,0,0) record
+    holey = np.ascontiguousarray(rec[keep])
+    w = fs.synth.make_workload("C1", n_cand=150)
+    poses = oracle.poses_from_yaw(w.goals, rng.uniform(-np.pi, np.pi, size=150))
+    _setup_scorer(scorer, w)
+    try:
+        scorer.lookup_set_records(holey)
+        table = oracle.Table.from_records(holey)
+        want = oracle.pose_information(table, w.landmarks, poses, 14.0, 1.0, n_threads=8)
+        full = oracle.pose_information(ref_table, w.landmarks, poses, 14.0, 1.0, n_threads=8)
+        assert (want["n_voxels"] < full["n_voxels"]).sum() > 100      # the holes matter
+        got = scorer.score_fim(poses)
+        _check_fim(got, want, w.landmarks.shape[0])
+        # the fused path uses the same table
+        G, P = _oracle_grid_params(oracle, w)
+        mx = scorer.max_arrival()
+        rec_gpu = scorer.score_candidates(w.goals, w.frontier_size, w.blacklisted)
+        arr = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx["min_gt"], n_threads=8)
+        ok = arr["status"] == 0
+        fim = oracle.pose_information(table, w.landmarks, oracle.poses_from_yaw(w.goals, arr["yaw"]), 14.0, 1.0, n_threads=8)
+        np.testing.assert_array_equal(rec_gpu["n_visible"][ok], fim["n_visible"][ok])
+        np.testing.assert_array_equal(((rec_gpu["flags"] >> 16) & 0xFFFF)[ok], fim["n_voxels"][ok])
+        sc = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
+        assert np.max(np.abs(rec_gpu["info_ref"][ok] - fim["info_f64"][ok]) / sc) <= REL
+    finally:
+        scorer.lookup_generate()

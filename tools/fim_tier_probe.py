@@ -12,7 +12,7 @@ sc.upload_grid(w.cells, w.origin, w.resolution); sc.upload_landmarks(w.landmarks
 sc.max_arrival()
 sc.enable_kernel_timing(True)
 ref = None
-for bits1, skip in [(14, 15), (14, 13), (14, 12), (14, 11), (14, 10), (14, 9), (14, 8), (14, 15)]:
+for bits1, skip in [(14, 12), (14, 14), (14, 11), (14, 10), (14, 9), (14, 12)]:
     sc.set_option("fim.bits1", bits1); sc.set_option("fim.skip32", skip)
     for rnd in range(3):
         for k in (0, 1, 2): sc.kernel_time(k)
