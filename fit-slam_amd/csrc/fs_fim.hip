@@ -33,6 +33,7 @@
 #define FS_NACC 18       // info, 15 FIM block sums, n_visible, n_voxels
 #define FS_QCAP 128      // per-wave compaction queue (<= 63 left over + 64 new)
 #define FS_MAX_PROBE 32  // LDS tiers give up (-> next tier) after this many bucket visits
+#define FS_MAX_PARTS 8   // scoring passes per candidate within one LDS tier
 
 #ifdef FS_FIM_STAMPS   // development: per-phase cycle counters of the tier-1 worker (tools/fim_stamps.py)
 #define FS_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); st[k] += now_ - tprev; tprev = now_; } while (0)
@@ -58,20 +59,12 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
     return (key * 2654435761u) >> (32 - bits);
 }
 
-// Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch).
-// Written as predicated straight-line code (selects, no per-lane branches): the scalar unit, not the vector ALU,
-// limited the branchy version.  TABLE_FULL (no NaN holes inside the table box: every generated table) removes the
-// only dependence of the hash update on the gathered table value, so that load is first waited for at the very end.
-// Returns true when this landmark opened a new voxel entry.
-template <bool TABLE_FULL>
-__device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
-                                              bool active, float px, float py, float pz, Acc &acc, bool &overflow)
+// Voxel lattice index of a camera-frame point -> key into the dense table: round(x * (1 / corrected_step)) of
+// getVoxelCoordinate (FisherInfoManager.hpp:119-121), exactly.  The fp32 product is within |r| * 1.3e-7 of the fp64
+// one (|r| < 2^10 checked), so away from a .5 boundary the fp32 nearest integer equals the fp64 half-away-from-zero
+// result; lanes next to a boundary (0.1 %) re-evaluate the fp64 expression.  in_table: the voxel lies inside the table box.
+__device__ __forceinline__ uint32_t voxel_key(const FsFimArgs &a, bool active, float px, float py, float pz, bool &in_table)
 {
-    acc.nvis += active ? 1 : 0;
-    // ---- voxel lattice index: round(x * (1 / corrected_step)) of getVoxelCoordinate (FisherInfoManager.hpp:119-121),
-    // exactly.  The fp32 product is within |r| * 1.3e-7 of the fp64 one (|r| < 2^10 checked), so away from a .5
-    // boundary the fp32 nearest integer equals the fp64 half-away-from-zero result; lanes next to a boundary
-    // (0.1 %) re-evaluate the fp64 expression.
     const float rx = px * a.inv_step_f, ry = py * a.inv_step_f, rz = pz * a.inv_step_f;
     const float nx = rintf(rx), ny = rintf(ry), nz = rintf(rz);
     int jx = (int)nx, jy = (int)ny, jz = (int)nz;
@@ -83,9 +76,35 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         jz = (int)round((double)pz * a.inv_step);
     }
     jx -= a.jx0; jy -= a.jy0; jz -= a.jz0;
-    const bool in_table = active && (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
+    in_table = active && (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
     // table extents are < 2^11 each and the cell count < 2^21 (FS_MAX_TABLE_CELLS): 24-bit multiplies are exact
-    const uint32_t key = in_table ? __umul24(__umul24((uint32_t)jx, (uint32_t)a.ty) + (uint32_t)jy, (uint32_t)a.tz) + (uint32_t)jz : 0u;
+    return in_table ? __umul24(__umul24((uint32_t)jx, (uint32_t)a.ty) + (uint32_t)jy, (uint32_t)a.tz) + (uint32_t)jz : 0u;
+}
+
+// Which of a candidate's n_parts (a power of two) scoring passes owns a landmark: the x index of its voxel, exactly as
+// voxel_key computes it, modulo n_parts — whole voxels go to one pass, neighbouring slabs of voxels alternate between
+// the passes (balanced), and only one coordinate has to be rounded.
+__device__ __forceinline__ int voxel_part(const FsFimArgs &a, bool active, float px, int n_parts)
+{
+    const float rx = px * a.inv_step_f;
+    const float nx = rintf(rx);
+    int jx = (int)nx;
+    if (active && !(fabsf(rx - nx) < 0.4995f && fabsf(rx) < 1024.0f)) jx = (int)round((double)px * a.inv_step);
+    return (jx + 4096) & (n_parts - 1);
+}
+
+// Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch).
+// Written as predicated straight-line code (selects, no per-lane branches): the scalar unit, not the vector ALU,
+// limited the branchy version.  TABLE_FULL (no NaN holes inside the table box: every generated table) removes the
+// only dependence of the hash update on the gathered table value, so that load is first waited for at the very end.
+// Returns true when this landmark opened a new voxel entry.
+template <bool TABLE_FULL>
+__device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
+                                              bool active, float px, float py, float pz, Acc &acc, bool &overflow)
+{
+    acc.nvis += active ? 1 : 0;
+    bool in_table;
+    const uint32_t key = voxel_key(a, active, px, py, pz, in_table);
     // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
     const float info_t = a.table[key];
 
@@ -201,10 +220,12 @@ struct FimWork {
 // finished its share of candidate i culls the chunks of candidate i+1 before it joins the reduction barrier, so the
 // latency of the sphere loads and the imbalance between waves overlap instead of adding up.  Two barriers per
 // candidate: after the table clear and after the reduction.
-template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL>
-__device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits,
-                                           const uint32_t fail_code)
+// FAIL_CODE: the tier a failed candidate is handed to (1: the second LDS tier, 2: the HBM tier, 3: nobody) — a
+// template parameter so that each tier only carries the code of its own hand-over rule.
+template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, uint32_t FAIL_CODE>
+__device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits)
 {
+    constexpr uint32_t fail_code = FAIL_CODE;
     constexpr int WAVES = THREADS / 64;
     constexpr int STRIDE = WAVES * 64;
     const uint32_t max_probe = GLOBAL_TABLE ? (1u << tier_bits) : FS_MAX_PROBE;   // bucket visits incl. re-reads
@@ -310,12 +331,27 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
         // ---- size and clear the hash table.  Distinct voxels are at most ~0.5 of the landmarks scanned (measured
         // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
-        // candidates clear only a small table.  A candidate predicted to overfill this tier's largest table goes
-        // straight to the next tier (only where that is another LDS tier: falling through to the HBM tier by
-        // prediction alone is too costly); the running voxel count in the main loop is the exact safety net.
-        const bool skip_tier = !GLOBAL_TABLE && fail_code == 1u && ((long long)wg_tested * 64 * a.skip32 > (long long)(3 << (tier_bits - 2)) * 32);
+        // candidates clear only a small table.  The running voxel count in the main loop is the exact safety net.
+        //
+        // The first tier hands a candidate predicted to overfill its table to the second one (a failed attempt would be
+        // wasted work, and heavy candidates at the end of this kernel would be its tail).  The second tier — the last
+        // one with an LDS table — scores a candidate that is too big even for its table in n_parts PASSES over the
+        // accepted chunks: every pass re-tests the landmarks but only queues those whose voxel belongs to the pass
+        // (voxel_part), so each landmark is still scored exactly once and each pass needs 1/n_parts of the table.
+        // That costs one extra test per landmark and pass, against a table in HBM with two dependent global atomics
+        // per landmark (measured on C5: 3x faster per candidate).
+        const long long capacity = 3ll << (tier_bits - 2);                           // 3/4 of the largest table
+        int n_parts = 1;
+        bool skip_tier = false;
+        if (!GLOBAL_TABLE && fail_code == 1u) {
+            skip_tier = (long long)wg_tested * 64 * a.skip32 > capacity * 32;
+        } else if (!GLOBAL_TABLE) {
+            const long long worst = (long long)wg_tested * 32;                        // distinct voxels <= 0.5 of the landmarks scanned
+            while (n_parts <= FS_MAX_PARTS && worst > capacity * n_parts) n_parts <<= 1;
+            skip_tier = n_parts > FS_MAX_PARTS;                                       // hopeless here: HBM tier
+        }
         int bits = tier_bits;
-        if (!GLOBAL_TABLE) {
+        if (!GLOBAL_TABLE && n_parts == 1) {
             int need = 10;
             while (need < tier_bits && (1 << need) < wg_tested * 64) ++need;
             bits = need;
@@ -355,18 +391,30 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         int qcount = 0;                                            // wave-uniform
         const unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
 
+        for (int part = 0; part < n_parts && !skip_tier; ++part) {
+        if (part > 0) {
+            // next pass: everybody is done with the table -> clear it, restart the running voxel count
+            __syncthreads();
+            const bool stop = *v_overflow != 0;                    // uniform: nobody writes the flag between these barriers
+            uint4 *t4 = reinterpret_cast<uint4 *>(table);
+            for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid == 0) sh_nvox[buf] = 0;
+            __syncthreads();
+            if (stop) break;                                       // an earlier pass ran out of table: next tier
+        }
         // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
         // next chunks' landmarks prefetched into registers while the current one is processed.
-        for (int g = 0; g < a.n_groups && !skip_tier; ++g) {
+        for (int g = 0; g < a.n_groups; ++g) {
             const int g0 = g * STRIDE;
             unsigned long long mask = masks[g];
             mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
             if (!GLOBAL_TABLE) {
                 if (*v_overflow) break;                            // another wave ran out of table: the next tier redoes it
-                // distinct voxels so far, extrapolated over the chunks still to come (Morton order interleaved over
-                // the waves makes the prefix representative): a table that clearly will not fit is handed on early
-                if (g > 0 && (long long)(*v_nvox) * a.n_chunks > (long long)nvox_limit * g0 * 5 / 4) { overflow = true; *v_overflow = 1; break; }
+                // First tier only: distinct voxels so far, extrapolated over the chunks still to come — a table that
+                // clearly will not fit is handed on early.  (The last LDS tier sizes its passes for the worst case and
+                // only stops on a real overflow: a false alarm there would cost a pass through the HBM tier.)
+                if (fail_code == 1u && g > 0 && (long long)(*v_nvox) * a.n_chunks > (long long)nvox_limit * g0 * 5 / 4) { overflow = true; *v_overflow = 1; break; }
             }
             auto pop = [&]() -> int {
                 if (!mask) return -1;
@@ -391,6 +439,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 bool vis = (n2 <= a.maxd2);
                 if (a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
                 else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px * px <= a.cos2 * n2));
+                if (n_parts > 1) vis = vis && voxel_part(a, vis, px, n_parts) == part;   // wave-uniform branch
                 // ---- 3. compact
                 const unsigned long long m = __ballot(vis);
                 if (m != 0ull) {
@@ -418,14 +467,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             }
         }
         FS_STAMP(2);
-        if (skip_tier) qcount = 0;
         // flush the queue remainder
         if (qcount > 0) {
             const bool have = lane < qcount;
             score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
+            qcount = 0;
         }
         if (overflow) *v_overflow = 1;
         FS_STAMP(3);
+        }   // passes
 
         // ---- the next candidate's cull fills the time this wave would otherwise wait for the slower ones
         if (tid == 0) sh_next[buf] = ahead;                        // read by the next iteration after its first barrier
@@ -460,7 +510,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         }
         if (tid == 0) {
             a.overflow[c] = failed ? fail_code : 0u;                  // the next tier re-scores flagged candidates
-            if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u);   // landmarks tested (M_tested), summed by the finish kernel
+            if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);   // landmarks tested (M_tested), summed by the finish kernel
             if (failed && fail_code < 3u) {
                 const unsigned long long slot = atomicAdd(&a.counters[fail_code], 1ull);
                 a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
@@ -473,7 +523,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         FS_STAMP(7);
     }
 #ifdef FS_FIM_STAMPS
-    if (lane == 0 && !GLOBAL_TABLE && fail_code == a.fail_code1) {
+    if (lane == 0 && !GLOBAL_TABLE && fail_code == a.fail_code1 && THREADS == FS_T1_THREADS) {
         for (int k = 0; k < 8; ++k) atomicAdd(&a.counters[16 + k], st[k]);
         atomicAdd(&a.counters[24], 1ull);
     }
@@ -481,13 +531,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 }
 
 // tier 1: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
-template <int THREADS, bool TABLE_FULL>
-__global__ __launch_bounds__(THREADS)
+// (two workgroups of 8 waves per CU = 4 waves per SIMD: the register allocator must stay within 128 VGPRs)
+template <int THREADS, bool TABLE_FULL, uint32_t FAIL_CODE>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
-    fim_worker<THREADS, false, TABLE_FULL>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits, a.fail_code1);
+    fim_worker<THREADS, false, TABLE_FULL, FAIL_CODE>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits);
 }
 
 // tier 2: candidates tier 1 appended to its work list, with a larger LDS table
@@ -497,7 +548,7 @@ void fs_fim_tier2_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.flagged, 0, (int)a.counters[1], a.counters + 7};
-    fim_worker<THREADS, false, TABLE_FULL>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2, 2u);
+    fim_worker<THREADS, false, TABLE_FULL, 2u>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2);
 }
 
 // tier 3: candidates on the second work list; table in HBM with 2x the landmark count of slots and unbounded probing
@@ -508,7 +559,7 @@ void fs_fim_tier3_kernel(const FsFimArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.flagged + a.n, 0, (int)a.counters[2], a.counters + 9};
     uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
-    fim_worker<THREADS, true, TABLE_FULL>(a, work, fs_fim_lds, table, a.ghash_bits, 3u);
+    fim_worker<THREADS, true, TABLE_FULL, 3u>(a, work, fs_fim_lds, table, a.ghash_bits);
 }
 
 // One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
@@ -623,11 +674,11 @@ size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks)
 
 namespace {
 
-template <bool TABLE_FULL>
+template <bool TABLE_FULL, uint32_t FAIL_CODE>
 hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
 {
     const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
-    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL>;
+    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, FAIL_CODE>;
     hipError_t e = allow_lds(kernel, lds);
     if (e != hipSuccess) return e;
     static int resident = 0;                                   // same kernel, same LDS budget class: query once
@@ -664,7 +715,8 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
     if (a0.n <= 0 || a0.cand_count <= 0) return hipSuccess;
     FsFimArgs a = a0;
-    return a.table_full ? launch_tier1<true>(a, s) : launch_tier1<false>(a, s);
+    if (a.fail_code1 == 1u) return a.table_full ? launch_tier1<true, 1u>(a, s) : launch_tier1<false, 1u>(a, s);
+    return a.table_full ? launch_tier1<true, 2u>(a, s) : launch_tier1<false, 2u>(a, s);
 }
 
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a0, int pool, hipStream_t s)

@@ -275,8 +275,9 @@ def test_fim_culling_is_exact(fs, oracle, scorer, ref_table):
         out[cull]["tested"] = scorer.get_counter(0, reset=True)
     scorer.set_option("fim.cull", 1)
     m_pad = -(-w.landmarks.shape[0] // 64) * 64
-    # every candidate tests the whole cloud once (a candidate re-scored by a larger hash tier tests it again)
-    assert 400 * m_pad <= out[0]["tested"] <= 1.05 * 400 * m_pad and out[0]["tested"] % m_pad == 0
+    # without culling every candidate tests the whole cloud once per scoring pass (a cloud of this size is predicted to
+    # overfill one LDS table, so the brute-force mode runs a few passes per candidate)
+    assert 400 * m_pad <= out[0]["tested"] <= 8 * 400 * m_pad and out[0]["tested"] % m_pad == 0
     assert out[1]["tested"] < 0.5 * out[0]["tested"]
     for k in ("n_visible", "n_voxels"):
         np.testing.assert_array_equal(out[0][k], out[1][k])
