@@ -154,7 +154,12 @@ __device__ __forceinline__ bool ray_setup(const FsRayArgs &a, bool start_ok, uin
 template <typename Walk>
 __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
 {
-    const int omin = a.obst_min, omax = a.obst_max, tmin = a.trace_min, tmax = a.trace_max;
+    // the visitor's inclusive ranges, intersected with the byte range of a cell, as one unsigned compare each; an empty
+    // range (e.g. the obstacle range (260, 260) of setMaxArrivalInformation) matches nothing
+    const int omin = a.obst_min > 0 ? a.obst_min : 0, omax = a.obst_max < 255 ? a.obst_max : 255;
+    const int tmin = a.trace_min > 0 ? a.trace_min : 0, tmax = a.trace_max < 255 ? a.trace_max : 255;
+    const bool o_any = omax >= omin, t_any = tmax >= tmin;
+    const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
     int count = 0;
     uint32_t visits = w.end + 1;          // loop visits + the one after the loop (Helpers.cpp:29)
     while (visits > 0) {
@@ -170,13 +175,15 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
                 walk_step(w);
             }
         }
+        // classify in order, without branches: a cell counts if no earlier cell of the ray was an obstacle
+        // (Helpers.hpp:64-71: the traced test comes before hit_obstacle is set, so an obstacle cell itself still counts
+        // when the two ranges overlap); slots past `nb` hold -1 and match no range
         bool hit = false;
 #pragma unroll
         for (int u = 0; u < FS_RAY_UNROLL; ++u) {
-            if ((uint32_t)u < nb && !hit) {
-                if (c[u] <= tmax && c[u] >= tmin) ++count;          // Helpers.hpp:64-67 (tested before hit is set)
-                if (c[u] >= omin && c[u] <= omax) hit = true;       // Helpers.hpp:68-71
-            }
+            const bool traced = t_any && !hit && (uint32_t)(c[u] - tmin) <= trange;
+            count += traced ? 1 : 0;
+            hit = hit || (o_any && (uint32_t)(c[u] - omin) <= orange);
         }
         if (hit) break;                    // nothing is pushed after the first obstacle
         visits -= nb;
