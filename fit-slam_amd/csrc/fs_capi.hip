@@ -1328,16 +1328,11 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     // the FIM kernel visits the candidates in the same spatial order: neighbouring poses walk the same landmark chunks
     rc = run_fim_tier1(c, fa, ra.perm, 0, n);
     if (rc) return rc;
+    // the finish kernel assembles the records (one launch less than a separate pack)
+    fa.records = d_records;
+    fa.rec_arrival = c->d_arrival.p; fa.rec_argmax = c->d_argmax.p; fa.rec_yaw = c->d_yaw.p; fa.rec_achievable = c->d_ach.p;
     rc = run_fim_rest(c, fa);
     if (rc) return rc;
-    FsPackArgs pa{};
-    pa.n = n;
-    pa.arrival = c->d_arrival.p; pa.argmax = c->d_argmax.p; pa.status = c->d_status.p;
-    pa.yaw = c->d_yaw.p; pa.achievable = c->d_ach.p;
-    pa.info_ref = c->d_info.p; pa.trace = c->d_trace.p; pa.logdet = c->d_logdet.p;
-    pa.n_visible = c->d_nvis.p; pa.n_voxels = c->d_nvox.p;
-    pa.records = d_records;
-    FS_HIP(c, fs_launch_pack(pa, c->stream));
     return FS_OK;
 }
 

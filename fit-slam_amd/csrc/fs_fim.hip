@@ -632,9 +632,25 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
             L[i][j] = s / ljj;
         }
     }
-    a.logdet[c] = pd ? (float)ld : -INFINITY;
+    const float logdet = pd ? (float)ld : -INFINITY;
+    const int nvox = (int)(S[17] + 0.5);
+    a.logdet[c] = logdet;
     a.n_visible[c] = nvis;
-    a.n_voxels[c] = (int)(S[17] + 0.5);
+    a.n_voxels[c] = nvox;
+    if (a.records) {                                         // same layout as fs_pack_kernel
+        fs_record r;
+        r.arrival = a.rec_arrival[c];
+        r.argmax = a.rec_argmax[c];
+        r.yaw = (float)a.rec_yaw[c];
+        r.info_ref = (float)S[0];
+        r.trace = (float)((A[0] + A[3] + A[5]) + (B[0] + B[3] + B[5]));
+        r.logdet = logdet;
+        r.n_visible = nvis;
+        const uint32_t nv = (uint32_t)nvox;
+        r.flags = (a.rec_achievable[c] ? FS_FLAG_ACHIEVABLE : 0u) | (((uint32_t)a.status[c] & 0xffu) << 8) |
+                  ((nv > 65535u ? 65535u : nv) << 16);
+        a.records[c] = r;
+    }
 }
 
 template <int THREADS>

@@ -139,6 +139,11 @@ struct FsFimArgs {
     uint32_t *overflow;        // [n] tier that must re-score the candidate (0 = done)
     int32_t *flagged;          // [2][n] work lists: candidates tier 1 / tier 2 hand to the next tier
     uint32_t *tested;          // [n] landmark tests spent on the candidate (all tiers); zeroed by the finish kernel
+    // fused scoring: the finish kernel also assembles the 32-byte records (nullptr: separate outputs only)
+    fs_record *records;
+    const int32_t *rec_arrival, *rec_argmax;
+    const double *rec_yaw;
+    const uint8_t *rec_achievable;
     unsigned long long *counters;   // [16]: 0 landmarks tested, 1..3 per-call tier failures, 4..6 their running totals, 7/8/9 work-list cursors of tier 2/1/3
     // hash tables
     int32_t hash_bits;         // tier 1 (LDS, 512-thread workgroups)
@@ -156,16 +161,6 @@ struct FsFimArgs {
 #define FS_SLOT_CNT_SAT  1024u  // counts beyond this contribute exactly 0.0f anyway
 #define FS_MAX_TABLE_CELLS ((1u << (32 - FS_SLOT_CNT_BITS)) - 2u)
 
-// record assembly
-struct FsPackArgs {
-    int32_t n;
-    const int32_t *arrival, *argmax, *status;
-    const double *yaw;
-    const uint8_t *achievable;
-    const float *info_ref, *trace, *logdet;
-    const int32_t *n_visible, *n_voxels;
-    fs_record *records;
-};
 
 // launchers (defined in the .hip files)
 hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s);
@@ -174,7 +169,6 @@ hipError_t fs_launch_sort_candidates(int32_t n, const double *d_goal, const FsGr
 hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);
-hipError_t fs_launch_pack(const FsPackArgs &a, hipStream_t s);
 hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hipStream_t s);
 size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks);   // dynamic + static LDS of the 1024-thread tier
 

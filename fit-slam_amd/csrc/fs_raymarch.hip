@@ -349,24 +349,6 @@ __global__ void fs_selftest_kernel(int32_t max_abs, double *out_sqrt, double *ou
     out_div[t] = (dist == 0.0) ? 1.0 : 40.0 / dist;
 }
 
-__global__ void fs_pack_kernel(const FsPackArgs p)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    fs_record r;
-    r.arrival = p.arrival[i];
-    r.argmax = p.argmax[i];
-    r.yaw = (float)p.yaw[i];
-    r.info_ref = p.info_ref ? p.info_ref[i] : 0.0f;
-    r.trace = p.trace ? p.trace[i] : 0.0f;
-    r.logdet = p.logdet ? p.logdet[i] : 0.0f;
-    r.n_visible = p.n_visible ? p.n_visible[i] : 0;
-    const uint32_t nv = p.n_voxels ? (uint32_t)p.n_voxels[i] : 0u;
-    r.flags = (p.achievable[i] ? FS_FLAG_ACHIEVABLE : 0u) | (((uint32_t)p.status[i] & 0xffu) << 8) |
-              ((nv > 65535u ? 65535u : nv) << 16);
-    p.records[i] = r;
-}
-
 }  // namespace
 
 hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
@@ -385,13 +367,6 @@ hipError_t fs_launch_segments(const FsSegArgs &a, hipStream_t s)
     if (a.n <= 0) return hipSuccess;
     if (a.bricked) hipLaunchKernelGGL(fs_segments_kernel<WalkBricked>, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(fs_segments_kernel<WalkLinear>, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t fs_launch_pack(const FsPackArgs &a, hipStream_t s)
-{
-    if (a.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fs_pack_kernel, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -36,41 +36,47 @@ __global__ void fs_sortkey_kernel(int32_t n, const double *goal, FsGridDev g, in
 }
 
 // exclusive scan of the histogram by one workgroup: cursor[b] = first position of bin b; the histogram is cleared for
-// the next call
+// the next call.  Wave w owns the bins [w * 2048, (w + 1) * 2048) as 8 rows of 64 uint4: every load and store is one
+// contiguous kilobyte.
 __global__ __launch_bounds__(1024)
 void fs_sortscan_kernel(uint32_t *hist, uint32_t *cursor)
 {
-    constexpr int PER = FS_SORT_BINS / 1024;
+    constexpr int ROWS = FS_SORT_BINS / (16 * 64 * 4);
     __shared__ uint32_t wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t v[PER], sum = 0;
-    uint4 *h4 = reinterpret_cast<uint4 *>(hist + tid * PER);   // one 128-byte line per thread
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist) + (size_t)wave * ROWS * 64 + lane;
+    uint4 q[ROWS];
+    uint32_t row_incl[ROWS];                                   // inclusive scan over the lanes of each row
 #pragma unroll
-    for (int k = 0; k < PER / 4; ++k) {
-        const uint4 q = h4[k];
-        h4[k] = make_uint4(0u, 0u, 0u, 0u);
-        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
-        sum += (q.x + q.y) + (q.z + q.w);
+    for (int j = 0; j < ROWS; ++j) {
+        q[j] = h4[j * 64];
+        h4[j * 64] = make_uint4(0u, 0u, 0u, 0u);
     }
-    uint32_t incl = sum;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
+    uint32_t carry = 0;                                        // bins of this wave before row j
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        uint32_t incl = (q[j].x + q[j].y) + (q[j].z + q[j].w);
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        row_incl[j] = carry + incl;
+        carry += __shfl(incl, 63);
     }
-    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 0) wave_tot[wave] = carry;
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wave_tot[w];
-    uint32_t run = base + incl - sum;
-    uint4 *c4 = reinterpret_cast<uint4 *>(cursor + tid * PER);
+    uint4 *c4 = reinterpret_cast<uint4 *>(cursor) + (size_t)wave * ROWS * 64 + lane;
 #pragma unroll
-    for (int k = 0; k < PER / 4; ++k) {
-        uint4 q;
-        q.x = run; run += v[4 * k];
-        q.y = run; run += v[4 * k + 1];
-        q.z = run; run += v[4 * k + 2];
-        q.w = run; run += v[4 * k + 3];
-        c4[k] = q;
+    for (int j = 0; j < ROWS; ++j) {
+        uint32_t run = base + row_incl[j] - ((q[j].x + q[j].y) + (q[j].z + q[j].w));
+        uint4 o;
+        o.x = run; run += q[j].x;
+        o.y = run; run += q[j].y;
+        o.z = run; run += q[j].z;
+        o.w = run;
+        c4[j * 64] = o;
     }
 }
 
