@@ -4,7 +4,7 @@
 // (FIP/src/fisher_information/FisherInfoManager.cpp:83-100,287-324) plus the per-landmark Jacobian/FIM
 // of FisherInformationHelpers.cpp:71-123, batched over candidate poses.
 //
-// Data: the landmark cloud is staged once (fs_upload_landmarks) in Morton order as SoA fp32 and cut
+// Data: the landmark cloud is staged once (fs_upload_landmarks) in k-d leaf order as SoA fp32 and cut
 // into chunks of 64 consecutive landmarks, each with a bounding sphere.  One workgroup scores one
 // candidate:
 //   1. cull   — chunk k belongs to wave (k mod waves); every lane tests one chunk sphere against the

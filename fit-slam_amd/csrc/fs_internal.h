@@ -103,7 +103,7 @@ hipError_t fs_launch_kf_info(const FsKfArgs &a, int pool, hipStream_t s);
 
 // ---- FIM kernel arguments ---------------------------------------------------------------------
 struct FsFimArgs {
-    // landmarks: Morton-ordered SoA, n_chunks chunks of 64 (the tail padded with far-away sentinels),
+    // landmarks: SoA in k-d leaf order, n_chunks chunks of 64 (the tail padded with far-away sentinels),
     // one bounding sphere (cx, cy, cz, r + safety margin) per chunk
     const float *lx, *ly, *lz;
     const float *spheres;      // [n_chunks][4]
