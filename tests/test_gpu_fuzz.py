@@ -1,0 +1,91 @@
+"""Randomised differential test: random grids, fans, visitors, clouds and visibility volumes through the C ABI against the
+oracle.  Same bar as test_gpu_parity.py: integers bit-exact, Fisher information within 1e-4."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _random_case(rng, fs):
+    nx, ny = int(rng.integers(9, 90)), int(rng.integers(9, 90))
+    nz = int(rng.choice([1, 1, 2, 5, 12]))
+    res = float(rng.choice([0.05, 0.1, 0.037]))
+    origin = (float(rng.uniform(-3, 0.5)), float(rng.uniform(-3, 0.5)), float(rng.uniform(-0.5, 0.0)) if nz > 1 else 0.0)
+    vals = np.array([0, 0, 0, 0, 255, 255, 255, 254, 253, 240, 100, 239], np.uint8)
+    cells = rng.choice(vals, size=(nz, ny, nx))
+    if rng.random() < 0.3:
+        cells[:] = 255
+        cells[:, ny // 2, :] = 254
+    n = int(rng.integers(1, 70))
+    lo = np.array(origin)
+    hi = lo + np.array([nx, ny, nz]) * res
+    goals = rng.uniform(lo - 0.2, hi + 0.2, size=(n, 3))
+    if nz == 1:
+        goals[:, 2] = origin[2]
+    goals[: n // 2] = np.clip(goals[: n // 2], lo + 1e-6, hi - 1e-6)       # at least half on the map
+    n_elev = 1 if nz == 1 else int(rng.integers(1, 4))
+    elev = tuple(sorted(rng.uniform(-0.4, 0.4, size=n_elev).tolist())) if nz > 1 else (0.0,)
+    use_delta = rng.random() < 0.5
+    ray = dict(max_camera_depth=float(rng.uniform(0.3, 5.0)), delta_theta=float(rng.uniform(0.07, 0.6)),
+               camera_fov=float(rng.uniform(0.3, 2.0)), robot_radius=float(rng.uniform(0.05, 0.8)),
+               n_rays=0 if use_delta else int(rng.integers(8, 80)), elev=elev,
+               obst=tuple(sorted(rng.integers(200, 262, size=2).tolist())) if rng.random() < 0.7 else (260, 260),
+               trace=tuple(sorted(rng.integers(0, 258, size=2).tolist())),
+               polygon=(lo[0] + rng.uniform(-1, 1), lo[1] + rng.uniform(-1, 1), hi[0] + rng.uniform(-1, 1), hi[1] + rng.uniform(-1, 1)))
+    if not use_delta:
+        ray["delta_theta"] = 2 * np.pi / ray["n_rays"]
+    m = int(rng.choice([0, 1, 63, 64, 65, 300, 2000]))
+    lm = rng.uniform(lo - 1.0, hi + 1.0, size=(m, 3)).astype(np.float32)
+    if m > 10 and rng.random() < 0.3:
+        lm[: m // 3] = lm[0]                                               # a crowded voxel
+    fim = dict(max_dist=float(rng.uniform(0.5, 16.0)), max_angle=float(rng.choice([0.3, 1.0, 1.5, 1.5707963, 2.2, 3.2, 4.0])))
+    return dict(cells=cells, origin=origin, res=res, goals=goals, ray=ray, lm=lm, fim=fim,
+                fsize=rng.integers(1, 30, size=n).astype(np.int32), black=(rng.random(n) < 0.1).astype(np.uint8),
+                achin=(rng.random(n) < 0.9).astype(np.uint8))
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_configuration(fs, oracle, scorer, ref_table, seed):
+    rng = np.random.default_rng(9000 + seed)
+    k = _random_case(rng, fs)
+    G = oracle.Grid(k["cells"], origin=k["origin"], resolution=k["res"])
+    P = oracle.RayParams(**k["ray"])
+    n_yaw = oracle.num_yaw_rays(k["ray"]["delta_theta"], k["ray"]["n_rays"])
+    window = int(k["ray"]["camera_fov"] / k["ray"]["delta_theta"])
+    if n_yaw < max(window, 1) or window < 1:
+        with pytest.raises(fs.FsError):
+            scorer.set_ray_params(**k["ray"])
+        return
+    scorer.set_ray_params(**k["ray"])
+    scorer.upload_grid(k["cells"], k["origin"], k["res"])
+    scorer.upload_landmarks(k["lm"])
+    scorer.set_fim_params(**k["fim"])
+    layout = int(rng.integers(0, 3))
+    scorer.set_option("ray.layout", layout)
+    try:
+        mx_o = oracle.max_arrival_information(G, P)
+        assert scorer.max_arrival() == mx_o
+        want = oracle.arrival_information(G, P, k["goals"], k["fsize"], k["black"], k["achin"], min_gt=mx_o["min_gt"], faithful=True)
+        got = scorer.score_arrival(k["goals"], k["fsize"], k["black"], k["achin"])
+        for f in ("status", "arrival", "argmax", "achievable", "ray_counts"):
+            np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+        np.testing.assert_array_equal(got["yaw"], want["yaw"])
+        # fused records: FIM at (goal, best yaw)
+        rec = scorer.score_candidates(k["goals"], k["fsize"], k["black"], k["achin"])
+        np.testing.assert_array_equal(rec["arrival"], want["arrival"])
+        np.testing.assert_array_equal((rec["flags"] >> 8) & 0xFF, want["status"])
+        ok = want["status"] == 0
+        poses = oracle.poses_from_yaw(k["goals"], want["yaw"])
+        fim = oracle.pose_information(ref_table, k["lm"], poses[ok], k["fim"]["max_dist"], k["fim"]["max_angle"], n_threads=4)
+        np.testing.assert_array_equal(rec["n_visible"][ok], fim["n_visible"])
+        np.testing.assert_array_equal(((rec["flags"] >> 16) & 0xFFFF)[ok], np.minimum(fim["n_voxels"], 65535))
+        sc = np.maximum(np.abs(fim["info_f64"]), 1e-6)
+        assert np.all(np.abs(rec["info_ref"][ok] - fim["info_f64"]) / sc <= REL)
+        tr = np.maximum(np.abs(fim["trace"]), 1e-6)
+        assert np.all(np.abs(rec["trace"][ok] - fim["trace"]) / tr <= REL)
+        assert not rec["info_ref"][~ok].any() and not rec["n_visible"][~ok].any()
+    finally:
+        scorer.set_option("ray.layout", 0)
