@@ -318,7 +318,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     __syncthreads();
 
 #ifdef FS_FIM_STAMPS
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 8: inside score calls of the loop, 9: their number
     unsigned long long tprev = __builtin_readcyclecounter();
 #endif
     while (cur >= 0) {
@@ -452,7 +452,13 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                         qcount -= 64;                              // take the newest 64: the remainder stays in place
                         const float ex = qx[qcount + lane], ey = qy[qcount + lane], ez = qz[qcount + lane];
                         // ---- 4. score
+#ifdef FS_FIM_STAMPS
+                        const unsigned long long ts_ = __builtin_readcyclecounter();
+#endif
                         const bool opened = score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
+#ifdef FS_FIM_STAMPS
+                        st[8] += __builtin_readcyclecounter() - ts_; st[9] += 1;
+#endif
                         const unsigned long long om = __ballot(opened);
                         if (!GLOBAL_TABLE && om != 0ull) {
                             int total = 0;
@@ -524,8 +530,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     }
 #ifdef FS_FIM_STAMPS
     if (lane == 0 && !GLOBAL_TABLE && fail_code == a.fail_code1 && THREADS == FS_T1_THREADS) {
-        for (int k = 0; k < 8; ++k) atomicAdd(&a.counters[16 + k], st[k]);
-        atomicAdd(&a.counters[24], 1ull);
+        for (int k = 0; k < 10; ++k) atomicAdd(&a.counters[16 + k], st[k]);
+        atomicAdd(&a.counters[31], 1ull);
     }
 #endif
 }

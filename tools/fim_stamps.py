@@ -10,14 +10,16 @@ sc.set_ray_params(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta
 sc.upload_grid(w.cells, w.origin, w.resolution); sc.upload_landmarks(w.landmarks); sc.lookup_generate(); sc.set_fim_params(14.0, 1.0)
 sc.max_arrival()
 for _ in range(3): sc.score_candidates(w.goals, w.frontier_size, w.blacklisted)
-for k in range(16, 25): sc.get_counter(k, True)
+for k in range(16, 32): sc.get_counter(k, True)
 reps = 5
 for _ in range(reps): sc.score_candidates(w.goals, w.frontier_size, w.blacklisted)
-st = [sc.get_counter(k) for k in range(16, 25)]
-waves = st[8]
+st = [sc.get_counter(k) for k in range(16, 32)]
+waves = st[15]
 names = ["top: sizes + table clear", "barrier after clear", "scoring loop", "flush", "cull of next candidate", "dpp reduce", "barrier after reduce", "outputs"]
 n_iter = reps * w.goals.shape[0] * 8      # wave-iterations (8 waves per candidate)
 tot = sum(st[:8])
 print("waves %d, cycle-counter ticks per candidate and wave (total %.0f):" % (waves, tot / n_iter))
 for k in range(8):
     print("  %-28s %9.0f  %5.1f %%" % (names[k], st[k] / n_iter, 100.0 * st[k] / tot))
+print("  of the scoring loop: %.0f ticks in %.2f score calls (%.0f each), the rest = chunk tests + compaction" % (
+    st[8] / n_iter, st[9] / n_iter, st[8] / max(1, st[9])))
