@@ -54,6 +54,13 @@ struct Acc {
     int nvis, nvox;
 };
 
+// base[idx] with a 32-bit BYTE offset: lets the load use the scalar-base + 32-bit vector-offset addressing form instead
+// of building a 64-bit address per lane (every array indexed this way is far below 4 GiB)
+__device__ __forceinline__ float ldg32(const float *__restrict__ base, uint32_t idx)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (idx << 2));
+}
+
 __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
 {
     return (key * 2654435761u) >> (32 - bits);
@@ -106,7 +113,7 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     bool in_table;
     const uint32_t key = voxel_key(a, active, px, py, pz, in_table);
     // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
-    const float info_t = a.table[key];
+    const float info_t = ldg32(a.table, key);
 
     bool valid = in_table;
     if (!TABLE_FULL) valid = valid && (info_t == info_t);
@@ -424,12 +431,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             };
             int c0 = pop(), c1 = pop();
             float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
-            if (c0 >= 0) { const int l = c0 * 64 + lane; x0 = LX[l]; y0 = LY[l]; z0 = LZ[l]; }
-            if (c1 >= 0) { const int l = c1 * 64 + lane; x1 = LX[l]; y1 = LY[l]; z1 = LZ[l]; }
+            if (c0 >= 0) { const uint32_t l = (uint32_t)(c0 * 64 + lane); x0 = ldg32(LX, l); y0 = ldg32(LY, l); z0 = ldg32(LZ, l); }
+            if (c1 >= 0) { const uint32_t l = (uint32_t)(c1 * 64 + lane); x1 = ldg32(LX, l); y1 = ldg32(LY, l); z1 = ldg32(LZ, l); }
             while (c0 >= 0) {
                 const int c2 = pop();
                 float x2 = 0.f, y2 = 0.f, z2 = 0.f;
-                if (c2 >= 0) { const int l = c2 * 64 + lane; x2 = LX[l]; y2 = LY[l]; z2 = LZ[l]; }
+                if (c2 >= 0) { const uint32_t l = (uint32_t)(c2 * 64 + lane); x2 = ldg32(LX, l); y2 = ldg32(LY, l); z2 = ldg32(LZ, l); }
                 // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
                 const float dx = x0 - t[0], dy = y0 - t[1], dz = z0 - t[2];
                 const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
