@@ -130,7 +130,8 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     // sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector has no Jacobian.
     {
         const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
-        const float q = (active && n2 > 0.0f) ? 1.0f / n2 : 0.0f;
+        // (hardware reciprocal, 1 ulp: these sums only feed trace / log det / the 6x6, all held to 1e-4)
+        const float q = (active && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f;
         const float qx = px * q, qy = py * q, qz = pz * q;
         const float xx = px * qx, yy = py * qy, zz = pz * qz;
         const float v[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
@@ -289,7 +290,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = (gb + u) * STRIDE + lane * WAVES + wave;
-                sp[u] = (gb + u < a.n_groups && j < a.n_chunks) ? spheres[j] : make_float4(0.f, 0.f, 0.f, -1.f);
+                sp[u] = (gb + u < a.n_groups && j < a.n_chunks)
+                            ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
+                            : make_float4(0.f, 0.f, 0.f, -1.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
