@@ -19,6 +19,8 @@ HEADERS = ["fs_internal.h", os.path.join("..", "..", "include", "fitslam_frontie
 # the specification; fused multiply-adds appear only where the code calls fma explicitly.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+if os.environ.get("FS_FIM_BOUNDS"):       # development: range-checked global accesses in the FIM kernels (counter 30)
+    HIPCC_FLAGS.append("-DFS_FIM_BOUNDS")
 if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counters of the FIM worker in counters 16..24
     HIPCC_FLAGS.append("-DFS_FIM_STAMPS")
 

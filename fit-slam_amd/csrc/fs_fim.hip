@@ -44,6 +44,12 @@
 #define FS_T1_THREADS 512
 #define FS_T2_THREADS 1024
 
+#ifdef FS_FIM_BOUNDS   // development: every global access is range-checked, violations are recorded in counters[30] and skipped
+#define FS_BOUND(ok, code) ((ok) ? true : (atomicMax(&a.counters[30], (unsigned long long)(code)), false))
+#else
+#define FS_BOUND(ok, code) true
+#endif
+
 namespace {
 
 struct Acc {
@@ -61,9 +67,11 @@ __device__ __forceinline__ float ldg32(const float *__restrict__ base, uint32_t 
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (idx << 2));
 }
 
+// bucket of a voxel key (< 2^21): multiplicative hashing with a 24-bit multiplier — v_mul_u32_u24 runs at full rate, a
+// full 32-bit multiply at a quarter of it; consecutive keys (neighbouring voxels along z) land ~10 buckets apart
 __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
 {
-    return (key * 2654435761u) >> (32 - bits);
+    return (uint32_t)__umul24(key, 0x9E3779u) >> (32 - bits);     // the cast matters: HIP declares __umul24 as returning int
 }
 
 // Voxel lattice index of a camera-frame point -> key into the dense table: round(x * (1 / corrected_step)) of
@@ -85,7 +93,7 @@ __device__ __forceinline__ uint32_t voxel_key(const FsFimArgs &a, bool active, f
     jx -= a.jx0; jy -= a.jy0; jz -= a.jz0;
     in_table = active && (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
     // table extents are < 2^11 each and the cell count < 2^21 (FS_MAX_TABLE_CELLS): 24-bit multiplies are exact
-    return in_table ? __umul24(__umul24((uint32_t)jx, (uint32_t)a.ty) + (uint32_t)jy, (uint32_t)a.tz) + (uint32_t)jz : 0u;
+    return in_table ? (uint32_t)__umul24((uint32_t)__umul24((uint32_t)jx, (uint32_t)a.ty) + (uint32_t)jy, (uint32_t)a.tz) + (uint32_t)jz : 0u;
 }
 
 // Which of a candidate's n_parts (a power of two) scoring passes owns a landmark: the x index of its voxel, exactly as
@@ -113,7 +121,7 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     bool in_table;
     const uint32_t key = voxel_key(a, active, px, py, pz, in_table);
     // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
-    const float info_t = ldg32(a.table, key);
+    const float info_t = FS_BOUND(key < (uint32_t)(a.tx * a.ty * a.tz), 1) ? ldg32(a.table, key) : 0.0f;
 
     bool valid = in_table;
     if (!TABLE_FULL) valid = valid && (info_t == info_t);
@@ -123,6 +131,7 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
     const uint32_t bmask = (1u << (bits - 2)) - 1u;
     uint32_t hb = hash_key(key, bits - 2);
+    if (!FS_BOUND(hb <= bmask, 5)) hb = 0u;
     uint4 bk = make_uint4(0u, 0u, 0u, 0u);
     if (valid) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
 
@@ -250,7 +259,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     auto fetch = [&]() -> int {                                    // thread 0 only
         const int i = (int)atomicAdd(work.counter, 1ull);
         if (i >= work.count) return -1;
-        return work.list ? work.list[work.lo + i] : work.lo + i;
+        const int cid = work.list ? work.list[work.lo + i] : work.lo + i;
+        return FS_BOUND(cid >= 0 && cid < a.n, 2) ? cid : -1;
     };
 
     // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass, four
@@ -258,6 +268,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // The pose record (R row-major, t) read here is handed to the scoring pass of the same candidate in registers.
     auto cull = [&](int c, int buf, float *Rn, float *tn) {
         unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
+        if (!FS_BOUND(c >= 0 && c < a.n, 6)) c = 0;
         const bool dead = a.status && a.status[c] != FS_STATUS_OK;
         const float4 r0 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[0];
         const float4 r1 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[1];
@@ -434,12 +445,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             };
             int c0 = pop(), c1 = pop();
             float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
-            if (c0 >= 0) { const uint32_t l = (uint32_t)(c0 * 64 + lane); x0 = ldg32(LX, l); y0 = ldg32(LY, l); z0 = ldg32(LZ, l); }
-            if (c1 >= 0) { const uint32_t l = (uint32_t)(c1 * 64 + lane); x1 = ldg32(LX, l); y1 = ldg32(LY, l); z1 = ldg32(LZ, l); }
+            if (c0 >= 0 && FS_BOUND(c0 < a.n_chunks, 3)) { const uint32_t l = (uint32_t)(c0 * 64 + lane); x0 = ldg32(LX, l); y0 = ldg32(LY, l); z0 = ldg32(LZ, l); }
+            if (c1 >= 0 && FS_BOUND(c1 < a.n_chunks, 3)) { const uint32_t l = (uint32_t)(c1 * 64 + lane); x1 = ldg32(LX, l); y1 = ldg32(LY, l); z1 = ldg32(LZ, l); }
             while (c0 >= 0) {
                 const int c2 = pop();
                 float x2 = 0.f, y2 = 0.f, z2 = 0.f;
-                if (c2 >= 0) { const uint32_t l = (uint32_t)(c2 * 64 + lane); x2 = ldg32(LX, l); y2 = ldg32(LY, l); z2 = ldg32(LZ, l); }
+                if (c2 >= 0 && FS_BOUND(c2 < a.n_chunks, 3)) { const uint32_t l = (uint32_t)(c2 * 64 + lane); x2 = ldg32(LX, l); y2 = ldg32(LY, l); z2 = ldg32(LZ, l); }
                 // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
                 const float dx = x0 - t[0], dy = y0 - t[1], dz = z0 - t[2];
                 const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
@@ -522,14 +533,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (tid < FS_NACC && !failed) {
             double x = 0.0;
             for (int w = 0; w < WAVES; ++w) x += (double)sh_red[w * FS_NACC + tid];
-            a.sums[(size_t)c * FS_NACC + tid] = x;
+            if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + tid] = x;
         }
         if (tid == 0) {
             a.overflow[c] = failed ? fail_code : 0u;                  // the next tier re-scores flagged candidates
             if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);   // landmarks tested (M_tested), summed by the finish kernel
             if (failed && fail_code < 3u) {
                 const unsigned long long slot = atomicAdd(&a.counters[fail_code], 1ull);
-                a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
+                if (FS_BOUND(slot < (unsigned long long)a.n, 4)) a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
             } else if (failed) {
                 atomicAdd(&a.counters[3], 1ull);
             }
