@@ -18,7 +18,12 @@ HEADERS = ["fs_internal.h", os.path.join("..", "..", "include", "fitslam_frontie
 # -ffp-contract=off: the ray set-up (fp64) and the landmark transform (fp32) must round exactly like
 # the specification; fused multiply-adds appear only where the code calls fma explicitly.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-               "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+               "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
+RESOURCES = os.path.join(CSRC, "kernel_resources.json")
+# The FIM workers run two 512-thread (or one 1024-thread) workgroups per CU = 4 waves per SIMD: more than 128 VGPRs
+# halves the occupancy, and a spill lands in the innermost loop.  The register allocation of these kernels has flipped
+# on innocent-looking edits, so the build checks it.
+RESOURCE_LIMITS = {"fs_fim_kernel": (128, 0), "fs_fim_tier2_kernel": (128, 0)}
 if os.environ.get("FS_FIM_BOUNDS"):       # development: range-checked global accesses in the FIM kernels (counter 30)
     HIPCC_FLAGS.append("-DFS_FIM_BOUNDS")
 if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counters of the FIM worker in counters 16..24
@@ -40,6 +45,42 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _parse_resource_remarks(text: str) -> dict:
+    """kernel -> {vgprs, sgprs, scratch, lds, occupancy} from clang's -Rpass-analysis=kernel-resource-usage remarks."""
+    import re
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.search(r"remark: +Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("sgprs", r"TotalSGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("lds", r"LDS Size \[bytes/block\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m:
+                cur[key] = int(m.group(1))
+    return out
+
+
+def _record_resources(src: str, usage: dict) -> None:
+    import json
+    allr = {}
+    if os.path.exists(RESOURCES):
+        try:
+            allr = json.load(open(RESOURCES))
+        except Exception:
+            allr = {}
+    allr[src] = usage
+    json.dump(allr, open(RESOURCES, "w"), indent=1, sort_keys=True)
+    for name, u in usage.items():
+        for key, (max_vgprs, max_scratch) in RESOURCE_LIMITS.items():
+            if key in name and (u.get("vgprs", 0) > max_vgprs or u.get("scratch", 0) > max_scratch):
+                raise RuntimeError(f"{src}: {name} uses {u.get('vgprs')} VGPRs and {u.get('scratch')} B of scratch per lane "
+                                   f"(limits {max_vgprs} / {max_scratch}): the register allocation regressed")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
@@ -53,7 +94,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd = [cc, *HIPCC_FLAGS, "-c", src_path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            usage = _parse_resource_remarks(res.stderr)
+            rest = "\n".join(l for l in res.stderr.splitlines() if "kernel-resource-usage" not in l and l.strip())
+            if rest:
+                print(rest, flush=True)
+            if res.returncode != 0:
+                raise subprocess.CalledProcessError(res.returncode, cmd)
+            _record_resources(src, usage)
         objs.append(obj)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:

@@ -79,3 +79,20 @@ def test_synth_is_deterministic(fs):
                 ((a.goals[:, 1] - a.origin[1]) / a.resolution).astype(int),
                 ((a.goals[:, 0] - a.origin[0]) / a.resolution).astype(int)]
     assert np.all(v == 0)          # candidates are free frontier cells
+
+
+def test_fim_kernels_keep_their_register_budget():
+    """The FIM workers need <= 128 VGPRs and no scratch to keep 4 waves per SIMD (the build records the compiler's
+    kernel-resource remarks and refuses to link a library that regressed)."""
+    import importlib
+    import json
+    b = importlib.import_module("fit-slam_amd._build")
+    b.build()
+    usage = json.load(open(b.RESOURCES))["fs_fim.hip"]
+    seen = 0
+    for name, u in usage.items():
+        for key, (max_vgprs, max_scratch) in b.RESOURCE_LIMITS.items():
+            if key in name:
+                seen += 1
+                assert u["vgprs"] <= max_vgprs and u["scratch"] <= max_scratch, (name, u)
+    assert seen >= 4
