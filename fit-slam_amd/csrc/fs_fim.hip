@@ -481,11 +481,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                         st[8] += __builtin_readcyclecounter() - ts_; st[9] += 1;
 #endif
                         const unsigned long long om = __ballot(opened);
-                        if (!GLOBAL_TABLE && om != 0ull) {
-                            int total = 0;
-                            if (lane == 0) total = atomicAdd(&sh_nvox[buf], (int)__popcll(om)) + (int)__popcll(om);
-                            if (__builtin_amdgcn_readfirstlane(total) > nvox_limit) overflow = true;
-                        }
+                        // running count of distinct voxels for the checks at the top of every cull pass (fire and forget:
+                        // nothing here waits for the LDS; a table that really fills up fails its probe limit first)
+                        if (!GLOBAL_TABLE && om != 0ull && lane == 0) atomicAdd(&sh_nvox[buf], (int)__popcll(om));
                         if (__any(overflow)) *v_overflow = 1;
                     }
                 }
