@@ -32,7 +32,7 @@
 
 #define FS_NACC 18       // info, 15 FIM block sums, n_visible, n_voxels
 #define FS_QCAP 128      // per-wave compaction queue (<= 63 left over + 64 new)
-#define FS_MAX_PROBE 32  // LDS tiers give up (-> next tier) after this many bucket visits
+#define FS_MAX_PROBE 64  // LDS tiers give up (-> next tier) after this many bucket visits
 #define FS_MAX_PARTS 8   // scoring passes per candidate within one LDS tier
 
 #ifdef FS_FIM_STAMPS   // development: per-phase cycle counters of the tier-1 worker (tools/fim_stamps.py)
@@ -68,10 +68,11 @@ __device__ __forceinline__ float ldg32(const float *__restrict__ base, uint32_t 
 }
 
 // bucket of a voxel key (< 2^21): multiplicative hashing with a 24-bit multiplier — v_mul_u32_u24 runs at full rate, a
-// full 32-bit multiply at a quarter of it; consecutive keys (neighbouring voxels along z) land ~10 buckets apart
+// full 32-bit multiply at a quarter of it.  The multiplier was picked among a dozen odd constants on the voxel sets of
+// the heaviest C3 candidates (longest probe chain at 89 % load: 12 bucket visits; 2654435761 as a 32-bit multiplier: 17).
 __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
 {
-    return (uint32_t)__umul24(key, 0x9E3779u) >> (32 - bits);     // the cast matters: HIP declares __umul24 as returning int
+    return (uint32_t)__umul24(key, 0x7FEB35u) >> (32 - bits);     // the cast matters: HIP declares __umul24 as returning int
 }
 
 // Voxel lattice index of a camera-frame point -> key into the dense table: round(x * (1 / corrected_step)) of
