@@ -152,3 +152,38 @@ def test_lookup_table_file_roundtrip(fs, c3, c3_scorer, tmp_path):
     np.testing.assert_array_equal(_int_view(before), _int_view(after))
     np.testing.assert_allclose(before["info_ref"], after["info_ref"], rtol=5e-6, atol=1e-6)
     assert abs(s.lookup_query([0.3, 0.0, 0.0]) - 24.222222) < 2e-6 and np.isnan(s.lookup_query([3.0, 15.0, 0.0]))
+
+
+def test_huge_cloud_takes_the_multi_pass_route(fs, oracle, ref_table):
+    """1.6 M landmarks: the 1024-thread tier's chunk masks no longer fit next to its table, so the 512-thread worker is
+    the last LDS tier and scores crowded poses in several voxel-partitioned passes (or hands them to the HBM tier);
+    49 cull passes per candidate."""
+    rng = np.random.default_rng(77)
+    m = 1_600_000
+    lm = rng.uniform(-30.0, 30.0, size=(m, 3)).astype(np.float32)
+    lm[:400_000] = (rng.normal(scale=2.5, size=(400_000, 3)) + np.array([6.0, 0.0, 0.0])).astype(np.float32)   # a crowded region
+    poses = np.zeros((12, 7))
+    poses[:, 6] = 1.0
+    poses[:4, :3] = rng.normal(scale=0.5, size=(4, 3))                                  # looking into the crowd
+    poses[4:, :3] = rng.uniform(-20, 20, size=(8, 3))
+    yaw = rng.uniform(-np.pi, np.pi, size=8)
+    poses[4:, 5] = np.sin(yaw / 2); poses[4:, 6] = np.cos(yaw / 2)
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.lookup_generate()
+        s.upload_landmarks(lm)
+        s.set_fim_params(14.0, 1.0)
+        got = s.score_fim(poses, want_fim=False)
+        want = oracle.pose_information(ref_table, lm, poses, 14.0, 1.0, n_threads=8)
+        assert want["n_visible"].max() > 100_000 and want["n_voxels"].max() > 12_288
+        np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
+        np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
+        sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
+        assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= 1e-4
+        tr = np.maximum(np.abs(want["trace"]), 1e-6)
+        assert np.max(np.abs(got["trace"] - want["trace"]) / tr) <= 1e-4
+        # the four poses inside the crowd (55 k distinct voxels, > 8 passes' worth by the worst-case estimate) go through
+        # the HBM tier; the others, up to 34 k voxels, are scored in passes
+        assert 1 <= s.get_counter(5) <= 6
+    finally:
+        s.close()
