@@ -203,6 +203,15 @@ def main():
                     traffic = tj.get("fs_fim_kernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu_util = None
+        vpath = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(vpath):
+            try:
+                vj = json.load(open(vpath))
+                if vj.get("workload") == args.workload and args.depth_cells in (0, 40):
+                    valu_util = vj["kernels"]["fs_fim_kernel"]["valu_utilisation"]
+            except Exception:
+                valu_util = None
         gpu_rec = shard.records_to_numpy(full) if not args.no_parity else None
         cpu, parity = (None, None)
         if world == 1 and args.cpu_seconds > 0:
@@ -223,8 +232,11 @@ def main():
                          "launches_per_step": launches_per_step,
                          "hash_tier2_candidates": tier2, "hash_tier3_candidates": tier3,
                          "avg_launch_ms": fim_ms / max(fim_n, 1), "launches": fim_n,
+                         "valu_utilisation": valu_util,
                          "note": "algorithmic bytes (SURVEY 8(d), M_tested measured) / hipEvent time; the landmark cloud is "
-                                 "served from L2 after the first touch, so algorithmic GB/s is not HBM traffic (see traffic)"},
+                                 "served from L2 after the first touch, so algorithmic GB/s is not HBM traffic (see traffic); the kernel "
+                                 "is bound by vector-ALU issue: valu_utilisation = SQ_ACTIVE_INST_VALU x 4 / SIMD cycles of the launch "
+                                 "(profiles/pmc_valu.json)"},
             "kernels_ms_per_step": {"fs_raymarch_kernel": ray_ms / args.steps, "fs_fim_kernel": fim_ms / args.steps,
                                     "fs_fim_overflow_kernel": ovf_ms / args.steps,
                                     "raymarch_algorithmic_GBps": (n_local * b_ray) / ((ray_ms / args.steps) * 1e-3) / 1e9 if ray_n else None},
