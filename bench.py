@@ -69,6 +69,9 @@ def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx):
     out = {"value": n_s / dt, "unit": "candidate-goals/s", "cores": 1, "kind": "port",
            "sample": f"first {n_s} of {n_total} candidates of the same workload, oracle/ C restatement "
                      f"(reference-faithful control flow), single thread, {dt:.1f} s"}
+    n_c = max(probe, n_s // 2)
+    dt_c, _, _ = run(0, n_c, 1, False)
+    out["clean_value"] = n_c / dt_c          # BASELINE.md `cpu_clean`: same results, no per-ray vectors / O(k^2) dedupe, one thread
     cores = min(16, os.cpu_count() or 1)     # the GPU box's CPU share for one GPU
     n_o = min(n_total, n_s * min(cores, 16))
     dt_o, _, _ = run(0, n_o, cores, False)
