@@ -128,7 +128,12 @@ def main():
     lo, hi = shard.shard_bounds(n_total, world, rank)
     cap = shard.shard_capacity(n_total, world)
 
-    stream = torch.cuda.current_stream(dev)
+    # One explicit stream for everything: the scorer launches on the stream handle it is given and torch (and RCCL's
+    # all-gather) orders its work after the CURRENT stream — so the current stream must be that same, non-default one
+    # (the default stream's handle is 0, which the C ABI takes as "create your own").
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     sc = fs.FrontierScorer(device=dev_index, stream=stream.cuda_stream)
     arrival_kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
                       robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)

@@ -1,0 +1,49 @@
+"""The N > 1 data path of bench.py on one GPU: scoring on an explicit torch stream followed by the RCCL all-gather of the
+32-byte records (a one-rank "nccl" group: same calls, same stream ordering, no second device needed)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_scoring_then_rccl_all_gather_on_one_stream(fs):
+    import torch
+    import torch.distributed as dist
+    shard = importlib.import_module("fit-slam_amd.shard")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        w = fs.synth.make_workload("C2", n_cand=3000)
+        stream = torch.cuda.Stream(device=dev)
+        prev = torch.cuda.current_stream(dev)
+        torch.cuda.set_stream(stream)
+        try:
+            sc = fs.FrontierScorer(device=0, stream=stream.cuda_stream)
+            sc.set_ray_params(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+                              robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+            sc.upload_grid(w.cells, w.origin, w.resolution); sc.upload_landmarks(w.landmarks); sc.lookup_generate()
+            sc.set_fim_params(14.0, 1.0); sc.max_arrival()
+            want = sc.score_candidates(w.goals, w.frontier_size, w.blacklisted)          # host-buffer entry point
+            n = w.goals.shape[0]
+            cap = shard.shard_capacity(n, 1)
+            d_goal = torch.from_numpy(w.goals).to(dev); d_fs = torch.from_numpy(w.frontier_size).to(dev)
+            d_bl = torch.from_numpy(w.blacklisted).to(dev)
+            for _ in range(3):                                                           # no host synchronisation in between
+                d_rec = torch.zeros((cap, 8), dtype=torch.int32, device=dev)
+                sc.score_candidates_dev(n, d_goal.data_ptr(), d_fs.data_ptr(), d_bl.data_ptr(), 0, d_rec.data_ptr())
+                full = shard.gather_records(d_rec, n)
+            got = shard.records_to_numpy(full)
+            for f in ("arrival", "argmax", "n_visible", "flags"):
+                np.testing.assert_array_equal(got[f], want[f])
+            np.testing.assert_allclose(got["info_ref"], want["info_ref"], rtol=5e-6, atol=1e-6)
+            sc.close()
+        finally:
+            torch.cuda.set_stream(prev)
+    finally:
+        dist.destroy_process_group()
