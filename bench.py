@@ -148,19 +148,35 @@ def main():
     d_goal = torch.from_numpy(w.goals[lo:hi].copy()).to(dev)
     d_fsize = torch.from_numpy(w.frontier_size[lo:hi].copy()).to(dev)
     d_black = torch.from_numpy(w.blacklisted[lo:hi].copy()).to(dev)
-    d_rec = torch.zeros((cap, 8), dtype=torch.int32, device=dev)
+    # two record buffers: the all-gather of batch k runs on the communicator's stream while batch k+1 is being scored
+    d_recs = [torch.zeros((cap, 8), dtype=torch.int32, device=dev) for _ in range(2)]
+    pending = [None, None]
+    state = {"k": 0, "full": None}
     n_local = hi - lo
 
     def step():
+        b = state["k"] & 1
+        state["k"] += 1
+        if pending[b] is not None:
+            pending[b].wait()                                        # the gather that last read this buffer is done
+            pending[b] = None
+        d_rec = d_recs[b]
         sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_rec.data_ptr())
         if world > 1:
             if args.backend == "nccl":
-                return shard.gather_records(d_rec, n_total)
+                state["full"], pending[b] = shard.gather_records(d_rec, n_total, async_op=True)
+                return state["full"]
             torch.cuda.synchronize(dev)
-            return shard.gather_records(d_rec.cpu(), n_total)       # gloo rehearsal: through host memory
-        return d_rec[:n_total]
+            state["full"] = shard.gather_records(d_rec.cpu(), n_total)   # gloo rehearsal: through host memory
+            return state["full"]
+        state["full"] = d_rec[:n_total]
+        return state["full"]
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)

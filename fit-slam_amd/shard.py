@@ -25,11 +25,14 @@ def shard_capacity(n: int, world: int) -> int:
     return (n + world - 1) // world
 
 
-def gather_records(local, n_total: int, group=None):
+def gather_records(local, n_total: int, group=None, async_op: bool = False):
     """All-gather per-rank record blocks into the full, order-preserving record list.
 
     local: torch int32 tensor [capacity, 8] (rows beyond this rank's share are padding) on the
-    device the process group communicates on.  Returns a tensor [n_total, 8] on every rank.
+    device the process group communicates on.  Returns a tensor [n_total, 8] on every rank; with
+    async_op=True returns (tensor, work): the collective is ordered after everything already queued on the
+    current stream and runs on the communicator's own stream, so the caller can queue the next batch's kernels
+    right away and `work.wait()` before it touches the result (or reuses `local`).
     """
     import torch
     import torch.distributed as dist
@@ -38,8 +41,10 @@ def gather_records(local, n_total: int, group=None):
     cap = local.shape[0]
     assert cap == shard_capacity(n_total, world), (cap, n_total, world)
     out = torch.empty((world * cap, RECORD_WORDS), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
     # blocks are contiguous ranges of the candidate list, so trimming the tail padding restores the order
+    if async_op:
+        return out[:n_total], work
     return out[:n_total]
 
 

@@ -34,11 +34,29 @@ def test_scoring_then_rccl_all_gather_on_one_stream(fs):
             cap = shard.shard_capacity(n, 1)
             d_goal = torch.from_numpy(w.goals).to(dev); d_fs = torch.from_numpy(w.frontier_size).to(dev)
             d_bl = torch.from_numpy(w.blacklisted).to(dev)
-            for _ in range(3):                                                           # no host synchronisation in between
-                d_rec = torch.zeros((cap, 8), dtype=torch.int32, device=dev)
-                sc.score_candidates_dev(n, d_goal.data_ptr(), d_fs.data_ptr(), d_bl.data_ptr(), 0, d_rec.data_ptr())
-                full = shard.gather_records(d_rec, n)
-            got = shard.records_to_numpy(full)
+            # as in bench.py: two record buffers, the gather of batch k is asynchronous and overlaps the scoring of
+            # batch k+1; no host synchronisation in between
+            bufs = [torch.zeros((cap, 8), dtype=torch.int32, device=dev) for _ in range(2)]
+            pending = [None, None]
+            outs = []
+            for k in range(5):
+                b = k & 1
+                if pending[b] is not None:
+                    pending[b].wait()
+                bufs[b].zero_()
+                sc.score_candidates_dev(n, d_goal.data_ptr(), d_fs.data_ptr(), d_bl.data_ptr(), 0, bufs[b].data_ptr())
+                full, pending[b] = shard.gather_records(bufs[b], n, async_op=True)
+                outs.append(full)
+            for p in pending:
+                p.wait()
+            torch.cuda.synchronize(dev)
+            got = shard.records_to_numpy(outs[-1])
+            # every batch scored the same list: integers identical, float sums equal up to their summation order
+            for full in outs[:-1] + [shard.gather_records(bufs[0], n)]:                    # ... and the blocking form
+                r = shard.records_to_numpy(full)
+                for f in ("arrival", "argmax", "n_visible", "flags"):
+                    np.testing.assert_array_equal(r[f], got[f])
+                np.testing.assert_allclose(r["info_ref"], got["info_ref"], rtol=5e-6, atol=1e-6)
             for f in ("arrival", "argmax", "n_visible", "flags"):
                 np.testing.assert_array_equal(got[f], want[f])
             np.testing.assert_allclose(got["info_ref"], want["info_ref"], rtol=5e-6, atol=1e-6)
