@@ -142,6 +142,12 @@ class FrontierScorer:
 
     def close(self):
         if getattr(self, "_h", None):
+            if os.environ.get("FS_FIM_BOUNDS"):
+                # library built with FS_FIM_BOUNDS=1 (range-checked global accesses): counter 30 holds the code of the
+                # first violated check, 0 if none
+                code = self.get_counter(30)
+                if code:
+                    raise FsError(f"FS_FIM_BOUNDS: range check {code} was violated in a FIM kernel")
             self._L.fs_ctx_destroy(self._h)
             self._h = None
 
