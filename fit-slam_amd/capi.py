@@ -142,12 +142,12 @@ class FrontierScorer:
 
     def close(self):
         if getattr(self, "_h", None):
-            if os.environ.get("FS_FIM_BOUNDS"):
-                # library built with FS_FIM_BOUNDS=1 (range-checked global accesses): counter 30 holds the code of the
-                # first violated check, 0 if none
-                code = self.get_counter(30)
-                if code:
-                    raise FsError(f"FS_FIM_BOUNDS: range check {code} was violated in a FIM kernel")
+            if os.environ.get("FS_BOUNDS"):
+                # library built with FS_BOUNDS=1 (range-checked global accesses): counters 29 (ray walks) and 30 (FIM
+                # kernels) hold the code of a violated check, 0 if none
+                ray, fim = self.get_counter(29), self.get_counter(30)
+                if ray or fim:
+                    raise FsError(f"FS_BOUNDS: range check violated (ray walk code {ray}, FIM kernel code {fim})")
             self._L.fs_ctx_destroy(self._h)
             self._h = None
 

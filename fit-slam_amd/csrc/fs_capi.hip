@@ -361,7 +361,7 @@ int use_bricks(const fs_ctx *c, double max_length_cells)
 FsGridDev grid_dev(const fs_ctx *c)
 {
     return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res,
-                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3};
+                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3, c->d_counters.p + 29};
 }
 
 // every upload path ends here: the ray kernels read the bricked copy
@@ -494,6 +494,13 @@ int fs_ctx_create(int device_id, void *stream, fs_ctx **out)
             return FS_E_HIP;
         }
         c->own_stream = true;
+    }
+    // device-side counters (fs_get_counter; 29 / 30: range checks of FS_BOUNDS builds)
+    if (c->d_counters.ensure(32) != hipSuccess ||
+        hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(unsigned long long), c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        fs_ctx_destroy(c);
+        return FS_E_HIP;
     }
     *out = c;
     return FS_OK;
@@ -976,11 +983,6 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
     while ((1ll << gb) < 2ll * std::max(m, 1)) ++gb;
     c->ghash_bits = gb;
     FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
-    if (!c->d_counters.p) {
-        FS_HIP(c, c->d_counters.ensure(32));
-        FS_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(unsigned long long), c->stream));
-        FS_HIP(c, hipStreamSynchronize(c->stream));
-    }
     c->have_lm = true;
     return FS_OK;
 }

@@ -19,6 +19,7 @@ struct FsGridDev {
     double res;
     const uint8_t *bricks;     // [ceil(nz/2)][by][bx][2][8][8]
     int32_t bx, by;            // bricks per row / per column: ceil(nx/8), ceil(ny/8)
+    unsigned long long *dbg;   // range-checked builds (FS_BOUNDS=1): where a walk that left the grid is recorded
 };
 
 #define FS_BRICK_BYTES 128

@@ -89,9 +89,18 @@ __device__ __forceinline__ void walk_step(WalkBricked &w)
 // The cell under the walk.  Both end points are on the map (worldToMap succeeded) and a Bresenham walk between two
 // cells never leaves their bounding box — each axis takes at most |d_axis| steps towards the end point — so every
 // visit, including the speculative ones (they stay within `visits`), is inside the grid.
-__device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkLinear &w) { return (int)g.cells[w.offset]; }
+__device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkLinear &w)
+{
+#ifdef FS_RAY_BOUNDS   // development: verify the claim above on every visit instead of relying on it
+    if (w.offset >= (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz) { atomicMax(g.dbg, 1ull); return 256; }
+#endif
+    return (int)g.cells[w.offset];
+}
 __device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkBricked &w)
 {
+#ifdef FS_RAY_BOUNDS
+    if ((uint32_t)w.x >= (uint32_t)g.nx || (uint32_t)w.y >= (uint32_t)g.ny || (uint32_t)w.z >= (uint32_t)g.nz) { atomicMax(g.dbg, 2ull); return 256; }
+#endif
     return (int)g.bricks[fs_brick_offset((uint32_t)g.bx, (uint32_t)g.by, (uint32_t)w.x, (uint32_t)w.y, (uint32_t)w.z)];
 }
 
