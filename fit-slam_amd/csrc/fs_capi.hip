@@ -123,6 +123,12 @@ struct fs_ctx {
     void *sort_scratch = nullptr;
     size_t sort_scratch_bytes = 0;
     DevBuf<int32_t> d_perm;
+    // scratch of the per-tick entry points (fs_trace_segments, fs_frontier_cells, fs_information_frontier_pair,
+    // fs_upload_grid_bricks): owned by the context and grown on demand, never allocated and freed per call
+    DevBuf<double> d_seg_start, d_seg_end, d_tri;
+    DevBuf<uint8_t> d_seg_ok, d_seg_hit, d_mask, d_brick_cells;
+    DevBuf<int32_t> d_seg_traced, d_seg_unknown, d_seg_all, d_brick_xyz, d_bad;
+    DevBuf<unsigned long long> d_count;
     bool opt_sort = true;
     int opt_layout = 0;            // 0 auto, 1 row-major walk, 2 bricked walk
 
@@ -529,6 +535,9 @@ void fs_ctx_destroy(fs_ctx *c)
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->sort_scratch) (void)hipFree(c->sort_scratch);
     c->d_perm.release();
+    c->d_seg_start.release(); c->d_seg_end.release(); c->d_tri.release(); c->d_seg_ok.release(); c->d_seg_hit.release();
+    c->d_mask.release(); c->d_brick_cells.release(); c->d_seg_traced.release(); c->d_seg_unknown.release();
+    c->d_seg_all.release(); c->d_brick_xyz.release(); c->d_bad.release(); c->d_count.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -678,9 +687,8 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
     FS_HIP(c, c->d_cells.ensure((size_t)total));
     FS_HIP(c, hipMemsetAsync(c->d_cells.p, default_value, (size_t)total, c->stream));
     if (n_bricks > 0) {
-        DevBuf<int32_t> d_xyz;
-        DevBuf<uint8_t> d_bc;
-        DevBuf<int32_t> d_bad;
+        DevBuf<int32_t> &d_xyz = c->d_brick_xyz, &d_bad = c->d_bad;
+        DevBuf<uint8_t> &d_bc = c->d_brick_cells;
         FS_HIP(c, d_xyz.ensure((size_t)n_bricks * 3)); FS_HIP(c, d_bc.ensure((size_t)n_bricks * 512)); FS_HIP(c, d_bad.ensure(1));
         FS_HIP(c, hipMemsetAsync(d_bad.p, 0, 4, c->stream));
         FS_HIP(c, hipMemcpyAsync(d_xyz.p, brick_xyz, sizeof(int32_t) * 3 * (size_t)n_bricks, hipMemcpyHostToDevice, c->stream));
@@ -689,7 +697,7 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
         int32_t bad = 0;
         FS_HIP(c, hipMemcpyAsync(&bad, d_bad.p, 4, hipMemcpyDeviceToHost, c->stream));
         FS_HIP(c, hipStreamSynchronize(c->stream));
-        d_xyz.release(); d_bc.release(); d_bad.release();
+        if (d_bc.cap > ((size_t)64 << 20)) { d_bc.release(); d_xyz.release(); }   // a whole-map brick list (C5: 385 MB) is not worth keeping
         if (bad) { c->have_grid = false; return fail(c, FS_E_INVALID, "a brick lies outside the grid"); }
     }
     {
@@ -711,8 +719,8 @@ int fs_frontier_cells(fs_ctx *c, int32_t lethal_threshold, uint8_t *mask, int64_
     FS_HIP(c, hipSetDevice(c->device));
     if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
     const size_t total = (size_t)c->nx * c->ny * c->nz;
-    DevBuf<uint8_t> d_mask;
-    DevBuf<unsigned long long> d_count;
+    DevBuf<uint8_t> &d_mask = c->d_mask;
+    DevBuf<unsigned long long> &d_count = c->d_count;
     if (mask) FS_HIP(c, d_mask.ensure(total));
     FS_HIP(c, d_count.ensure(1));
     FS_HIP(c, hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), c->stream));
@@ -724,7 +732,6 @@ int fs_frontier_cells(fs_ctx *c, int32_t lethal_threshold, uint8_t *mask, int64_
     FS_HIP(c, hipMemcpyAsync(&n, d_count.p, sizeof n, hipMemcpyDeviceToHost, c->stream));
     if (mask) FS_HIP(c, hipMemcpyAsync(mask, d_mask.p, total, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
-    d_mask.release(); d_count.release();
     *count = (int64_t)n;
     return FS_OK;
 }
@@ -865,9 +872,9 @@ int fs_trace_segments(fs_ctx *c, int32_t n, const double *start_xyz, const doubl
     if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
     if (n < 0 || (n > 0 && (!start_xyz || !end_xyz || !ok || !traced || !hit || !unknown || !all))) return fail(c, FS_E_INVALID, "null pointer");
     if (n == 0) return FS_OK;
-    DevBuf<double> d_s, d_e;
-    DevBuf<uint8_t> d_ok, d_hit;
-    DevBuf<int32_t> d_tr, d_un, d_all;
+    DevBuf<double> &d_s = c->d_seg_start, &d_e = c->d_seg_end;
+    DevBuf<uint8_t> &d_ok = c->d_seg_ok, &d_hit = c->d_seg_hit;
+    DevBuf<int32_t> &d_tr = c->d_seg_traced, &d_un = c->d_seg_unknown, &d_all = c->d_seg_all;
     FS_HIP(c, d_s.ensure((size_t)n * 3)); FS_HIP(c, d_e.ensure((size_t)n * 3));
     FS_HIP(c, d_ok.ensure(n)); FS_HIP(c, d_hit.ensure(n)); FS_HIP(c, d_tr.ensure(n)); FS_HIP(c, d_un.ensure(n)); FS_HIP(c, d_all.ensure(n));
     FS_HIP(c, hipMemcpyAsync(d_s.p, start_xyz, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -885,7 +892,6 @@ int fs_trace_segments(fs_ctx *c, int32_t n, const double *start_xyz, const doubl
     FS_HIP(c, hipMemcpyAsync(unknown, d_un.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipMemcpyAsync(all, d_all.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
-    d_s.release(); d_e.release(); d_ok.release(); d_hit.release(); d_tr.release(); d_un.release(); d_all.release();
     return FS_OK;
 }
 
@@ -1180,7 +1186,7 @@ int fs_information_frontier_pair(fs_ctx *c, int32_t n, const double *est_pose7, 
     if (n == 0) return FS_OK;
     std::vector<float> Rt((size_t)n * 12);
     for (int32_t i = 0; i < n; ++i) pose_to_rt(est_pose7 + 7 * (size_t)i, &Rt[12 * (size_t)i]);
-    DevBuf<double> d_tri;
+    DevBuf<double> &d_tri = c->d_tri;
     FS_HIP(c, c->d_Rt.ensure(Rt.size())); FS_HIP(c, d_tri.ensure((size_t)n * 6)); FS_HIP(c, c->d_info.ensure(n));
     FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, Rt.data(), Rt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     FS_HIP(c, hipMemcpyAsync(d_tri.p, triangle_xy, sizeof(double) * 6 * (size_t)n, hipMemcpyHostToDevice, c->stream));
@@ -1188,7 +1194,6 @@ int fs_information_frontier_pair(fs_ctx *c, int32_t n, const double *est_pose7, 
     FS_HIP(c, fs_launch_frontier_pair(n, c->d_lx.p, c->d_ly.p, c->d_lz.p, c->n_chunks * FS_CHUNK, c->d_Rt.p, d_tri.p, c->d_info.p, c->stream));
     FS_HIP(c, hipMemcpyAsync(information, c->d_info.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
-    d_tri.release();
     return FS_OK;
 }
 

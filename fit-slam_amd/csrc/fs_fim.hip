@@ -132,7 +132,8 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
     const uint32_t bmask = (1u << (bits - 2)) - 1u;
     uint32_t hb = hash_key(key, bits - 2);
-    if (!FS_BOUND(hb <= bmask, 5)) hb = 0u;
+    (void)FS_BOUND(hb <= bmask, 5);
+    hb &= bmask;      // whatever the hash returns, the bucket index stays inside the table ("the 06:07 abort")
     uint4 bk = make_uint4(0u, 0u, 0u, 0u);
     if (valid) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
 

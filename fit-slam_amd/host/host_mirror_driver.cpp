@@ -85,7 +85,10 @@ int main(int argc, char **argv)
     if (single != info[0] || safe != (single > 550.0f)) ++failures;
 
     // key-frame pose information (computeInformationForPose): the first 20 frontier poses act as key-frames, landmark j
-    // is a word point of key-frame j % 20
+    // is a word point of key-frame j % 20.  setMapData pairs graph pose i with the node of the same id
+    // (getNodeDataAndOptTransform, deprecated/util.hpp:791-818), so the node list is deliberately NOT in pose order:
+    // nodes are stored in reverse, one more graph pose (id 999) has no node data at all (it is a key-frame without
+    // points), and a second node re-uses id 100 with junk points far away — the first node of that id in list order wins.
     std::vector<float> kf_info;
     {
         slam_msgs_lite::MapData map_data;
@@ -94,13 +97,38 @@ int main(int argc, char **argv)
             PoseStamped ps; ps.pose = poses[k];
             map_data.graph.poses.push_back(ps);
             map_data.graph.poses_id.push_back(100 + k);
+        }
+        for (int k = n_kf - 1; k >= 0; --k) {
             slam_msgs_lite::KeyFrame kf; kf.id = 100 + k;
             for (int32_t j = k; j < m; j += n_kf) { Point w; w.x = lm[3 * j]; w.y = lm[3 * j + 1]; w.z = lm[3 * j + 2]; kf.word_pts.push_back(w); }
             map_data.nodes.push_back(kf);
         }
+        if (n > n_kf) {
+            PoseStamped ps; ps.pose = poses[n_kf];
+            map_data.graph.poses.push_back(ps);
+            map_data.graph.poses_id.push_back(999);
+        }
+        {
+            slam_msgs_lite::KeyFrame junk; junk.id = 100;
+            for (int j = 0; j < 50; ++j) { Point w; w.x = poses[0].position.x + 0.01 * j; w.y = poses[0].position.y; w.z = 0.5; junk.word_pts.push_back(w); }
+            map_data.nodes.push_back(junk);
+        }
         frontier_exploration_information_affine::setMapData(*ctx, map_data);
         kf_info = frontier_exploration_information_affine::computeInformationForPoses(*ctx, poses, 2.0, 1.089, 0.5, 0.01f, 4.5);
         printf("computeInformationForPoses: pose0 %.4f\n", kf_info[0]);
+    }
+
+    // FrontierRoadMap::isConnectable for the pairs (i, i + 7): radius_to_decide_edges 6.1 m (DEP/params/exploration.yaml),
+    // max_connection_length = 1.5 x that (FrontierRoadmap.cpp:21)
+    std::vector<bool> connectable;
+    {
+        std::vector<std::pair<FrontierPtr, FrontierPtr>> pairs;
+        for (int32_t i = 0; i < n; ++i) pairs.emplace_back(req->frontier_list[i], req->frontier_list[(i + 7) % n]);
+        connectable = isConnectable(*ctx, *costmap, pairs, 6.1 * 1.5, 6.1);
+        size_t yes = 0;
+        for (bool b : connectable) yes += b;
+        printf("isConnectable: %zu of %zu pairs\n", yes, connectable.size());
+        if (connectable.size() != (size_t)n) ++failures;
     }
 
     // error behaviour of the reference interface
@@ -123,10 +151,10 @@ int main(int argc, char **argv)
     if (!o) { perror("result"); return 2; }
     for (int32_t i = 0; i < n; ++i) {
         const auto &fr = res_->frontier_list[i];
-        const double row[9] = {res_->frontier_arrival_information[i], fr->getGoalYaw(), (double)fr->isAchievable(),
-                               res_->frontier_costs[i], fr->getCost("arrival_gain_utility"), fr->getCost("distance_utility"),
-                               res_->frontier_distances[i], (double)info[i], (double)kf_info[i]};
-        fwrite(row, sizeof(double), 9, o);
+        const double row[10] = {res_->frontier_arrival_information[i], fr->getGoalYaw(), (double)fr->isAchievable(),
+                                res_->frontier_costs[i], fr->getCost("arrival_gain_utility"), fr->getCost("distance_utility"),
+                                res_->frontier_distances[i], (double)info[i], (double)kf_info[i], (double)connectable[i]};
+        fwrite(row, sizeof(double), 10, o);
     }
     fclose(o);
     printf("failures: %d\n", failures);

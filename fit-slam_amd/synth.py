@@ -33,6 +33,10 @@ CONFIGS = {
     # configs[4]: 1024^3 map (sparse brick list on the wire, dense 1 GiB in HBM), 50 k candidates, 500 k landmarks
     "C5": dict(index=5, n=1024, nz=1024, n_cand=50_000, n_landmarks=500_000, n_yaw=64,
                elev=(-0.30, -0.10, 0.10, 0.30), depth_cells=40),
+    # the reference's own operating point (DEP/src/CostCalculator.cpp:36, DEP/params/exploration.yaml:8-10): a 2-D costmap,
+    # delta_theta 0.10 accumulated while theta <= 2 pi (n_yaw = 0 selects that loop: 63 rays), one ring, L = 40
+    "REF2D": dict(index=6, n=512, nz=1, n_cand=20_000, n_landmarks=100_000, n_yaw=0, elev=(0.0,), depth_cells=40,
+                  reach=6, jitter=True),
 }
 
 RESOLUTION = 0.05
@@ -133,7 +137,9 @@ def make_grid(rng: np.random.Generator, n: int, nz: int) -> np.ndarray:
     return cells
 
 
-def _frontier_cells(rng: np.random.Generator, cells: np.ndarray, n_cand: int) -> np.ndarray:
+def _frontier_cells(rng: np.random.Generator, cells: np.ndarray, n_cand: int, reach: int = 1) -> np.ndarray:
+    """Free cells with an unknown cell within `reach` 4-neighbour steps in the plane (reach 1 = the frontier-cell
+    predicate itself; larger values add the cells around a frontier where cluster goal points fall)."""
     nz, ny, nx = cells.shape
     layers = np.arange(nz) if nz <= 64 else np.sort(rng.choice(nz, size=64, replace=False))
     found = []
@@ -143,11 +149,13 @@ def _frontier_cells(rng: np.random.Generator, cells: np.ndarray, n_cand: int) ->
         if not free.any():
             continue
         unk = s == 255
-        nb = np.zeros_like(free)
-        nb[1:, :] |= unk[:-1, :]
-        nb[:-1, :] |= unk[1:, :]
-        nb[:, 1:] |= unk[:, :-1]
-        nb[:, :-1] |= unk[:, 1:]
+        for _ in range(reach):
+            nb = np.zeros_like(free)
+            nb[1:, :] |= unk[:-1, :]
+            nb[:-1, :] |= unk[1:, :]
+            nb[:, 1:] |= unk[:, :-1]
+            nb[:, :-1] |= unk[:, 1:]
+            unk = unk | nb
         yy, xx = np.nonzero(free & nb)
         if yy.size:
             found.append(np.stack([xx, yy, np.full_like(xx, z)], axis=1))
@@ -187,19 +195,34 @@ def make_workload(name: str, *, n_cand: int | None = None, n_landmarks: int | No
     cells = make_grid(rng, n, nz)
     nc = cfg["n_cand"] if n_cand is None else n_cand
     m = cfg["n_landmarks"] if n_landmarks is None else n_landmarks
-    fc = _frontier_cells(rng, cells, nc)
+    fc = _frontier_cells(rng, cells, nc, reach=cfg.get("reach", 1))
     goals = (fc + 0.5) * res + np.asarray(origin)[None]
     if nz == 1:
         goals[:, 2] = origin[2]
+    if cfg.get("jitter"):
+        goals[:, :2] += rng.uniform(-0.5, 0.5, size=(nc, 2)) * res      # goal points are not cell centres in the reference
     fsize = rng.integers(1, 31, size=nc).astype(np.int32)
     black = (rng.random(nc) < 0.01).astype(np.uint8)
     lm = _landmarks(rng, cells, origin, res, m)
+    if nz == 1:
+        lm[:, 2] = rng.uniform(0.0, 2.5, size=lm.shape[0]).astype(np.float32)      # heights U(0, 2.5 m)
     n_yaw = cfg["n_yaw"]
     return Workload(name=name, cells=cells, origin=origin, resolution=res,
                     goals=np.ascontiguousarray(goals, dtype=np.float64), frontier_size=fsize, blacklisted=black,
                     landmarks=lm, n_yaw=n_yaw, elev=tuple(cfg["elev"]),
-                    max_camera_depth=cfg["depth_cells"] * res, delta_theta=2 * np.pi / n_yaw,
+                    max_camera_depth=cfg["depth_cells"] * res, delta_theta=(2 * np.pi / n_yaw) if n_yaw else 0.10,
                     polygon=(origin[0], origin[1], origin[0] + n * res, origin[1] + n * res))
+
+
+def dense_to_bricks(cells: np.ndarray, default_value: int = 255):
+    """Sparse wire format of fs_upload_grid_bricks (BASELINE.json configs[4]): the 8x8x8 bricks that hold anything but
+    `default_value`.  Returns (brick_xyz int32 [n][3] in brick units, brick_cells uint8 [n][512], index (z*8 + y)*8 + x)."""
+    nz, ny, nx = cells.shape
+    assert nz % 8 == 0 and ny % 8 == 0 and nx % 8 == 0
+    c = cells.reshape(nz // 8, 8, ny // 8, 8, nx // 8, 8).transpose(0, 2, 4, 1, 3, 5).reshape(-1, 512)
+    idx = np.nonzero((c != default_value).any(axis=1))[0]
+    bz, by, bx = np.unravel_index(idx, (nz // 8, ny // 8, nx // 8))
+    return np.stack([bx, by, bz], axis=1).astype(np.int32), np.ascontiguousarray(c[idx])
 
 
 def make_small_2d(seed: int, n: int = 96, n_cand: int = 64, n_landmarks: int = 600) -> Workload:

@@ -1,0 +1,64 @@
+"""Round-2 hardening checks: the host-side table generator against the oracle's record list
+byte for byte, and the per-tick entry points on context-owned scratch (growing, shrinking and interleaved calls)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_generated_lookup_records_equal_the_oracle_byte_for_byte(fs, oracle, ref_table):
+    """generateLookupTable (FIP/src/fisher_information/FisherInfoManager.cpp:117-229): same record sequence, same float32
+    bits — key order, de-duplication, the NaN skip at the origin and the trailing (0,0,0) <- max record included."""
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.lookup_generate()                                               # gen_fi_lookup's bounds
+        got = s.lookup_records()
+        want = ref_table.records
+        assert got.shape == want.shape == (710_000, 4)
+        assert got.tobytes() == want.tobytes()
+        for bounds in ((0.0, 3.0, -2.0, 2.0, -1.0, 1.0), (-1.2, 2.05, -0.31, 0.29, 0.0, 0.9), (0.0, 21.0, -14.7, 14.7, -14.7, 14.7)):
+            s.lookup_generate(bounds)
+            t = oracle.Table.generate(bounds)
+            assert s.lookup_records().tobytes() == t.records.tobytes(), bounds
+        # set_records / get_records round trip keeps the bytes (what fs_lookup_save writes)
+        s.lookup_set_records(want[::-1].copy())
+        assert s.lookup_records().tobytes() == want[::-1].tobytes()
+    finally:
+        s.close()
+
+
+def test_per_tick_entry_points_reuse_context_scratch(fs, oracle):
+    """fs_trace_segments / fs_frontier_cells / fs_information_frontier_pair keep their device buffers in the context:
+    calls of growing, shrinking and interleaved sizes must all stay correct."""
+    rng = np.random.default_rng(91)
+    w = fs.synth.make_small_2d(61, n=160, n_cand=8, n_landmarks=700)
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.upload_grid(w.cells, w.origin, w.resolution)
+        s.upload_landmarks(w.landmarks)
+        G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
+        lo = np.array(w.origin); hi = lo + np.array([160, 160, 1]) * w.resolution
+        want_mask = oracle.frontier_cell_mask(w.cells, 160)
+        for n in (5, 900, 37, 2_000, 1):
+            a = rng.uniform(lo, hi, size=(n, 3)); b = a + rng.normal(scale=1.0, size=(n, 3))
+            a[:, 2] = 0.0; b[:, 2] = 0.0
+            got = s.trace_segments(a, b, 122, obst=(253, 254), trace=(0, 255))
+            for i in range(0, n, max(1, n // 40)):
+                r = oracle.trace_ray(G, a[i], b[i], 122, obst=(253, 254), trace=(0, 255), faithful=True)
+                assert bool(got["ok"][i]) == r["ok"]
+                if r["ok"]:
+                    assert (got["traced"][i], bool(got["hit"][i]), got["unknown"][i], got["all"][i]) == (r["traced"], r["hit"], r["unknown"], r["all"])
+            mask, count = s.frontier_cells(w.cells.shape, 160, want_mask=(n % 2 == 1))
+            assert count == int(want_mask.sum())
+            if mask is not None:
+                np.testing.assert_array_equal(mask, want_mask)
+            k = max(1, n // 50)
+            poses = np.zeros((k, 7)); poses[:, 6] = 1.0
+            poses[:, :2] = rng.uniform(-2, 2, size=(k, 2))
+            tri = np.tile(np.array([[-3.0, -3.0, 3.0, -3.0, 0.0, 3.0]]), (k, 1)) + rng.normal(scale=0.2, size=(k, 6))
+            info = s.information_frontier_pair(poses, tri)
+            for i in range(k):
+                want = oracle.information_frontier_pair(w.landmarks, poses[i], tri[i].reshape(3, 2))
+                assert abs(info[i] - want) <= 1e-4 * max(1.0, abs(want))
+    finally:
+        s.close()

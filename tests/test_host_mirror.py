@@ -67,7 +67,7 @@ def test_get_frontier_costs_and_pose_safety(fs, oracle, ref_table, tmp_path):
     print(p.stdout, p.stderr)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "DID NOT THROW" not in p.stdout and "failures: 0" in p.stdout
-    got = np.fromfile(out, dtype=np.float64).reshape(-1, 9)
+    got = np.fromfile(out, dtype=np.float64).reshape(-1, 10)
 
     G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
     P = oracle.RayParams(polygon=poly32)
@@ -96,9 +96,20 @@ def test_get_frontier_costs_and_pose_safety(fs, oracle, ref_table, tmp_path):
     assert np.max(np.abs(got[:, 7] - fim["info_f64"]) / sc) <= 1e-4
     # computeInformationForPoses: the first 20 poses are the key-frames, landmark j belongs to key-frame j % 20
     poses = oracle.poses_from_yaw(w.goals, arr["yaw"])
+    # (the driver stores the nodes in reverse order, adds a 21st graph pose without node data and a junk node that
+    # re-uses id 100: setMapData must pair poses and nodes by id, first node of an id wins)
     n_kf = min(20, n)
-    per_kf = [w.landmarks[k::n_kf] for k in range(n_kf)]
+    per_kf = [w.landmarks[k::n_kf] for k in range(n_kf)] + [w.landmarks[:0]]
     off = np.concatenate([[0], np.cumsum([len(p) for p in per_kf])]).astype(np.int32)
-    kf = oracle.information_for_pose(G, poses, poses[:n_kf], off, np.concatenate(per_kf), 2.0, 1.089, 0.5, 0.01, 4.5)
+    kf = oracle.information_for_pose(G, poses, poses[:n_kf + 1], off, np.concatenate(per_kf), 2.0, 1.089, 0.5, 0.01, 4.5)
     assert kf["n_points"].sum() > 100
     np.testing.assert_allclose(got[:, 8], kf["info_f64"], rtol=1e-4, atol=1e-6)
+    # isConnectable(frontier i, frontier i + 7) (DEP/src/planners/FrontierRoadmap.cpp:716-737)
+    max_len = int((6.1 * 1.5) / w.resolution)
+    want_conn = np.zeros(n)
+    for i in range(n):
+        a, b = w.goals[i], w.goals[(i + 7) % n]
+        r = oracle.trace_ray(G, (a[0], a[1], 0.0), (b[0], b[1], 0.0), max_len, obst=(253, 254), trace=(0, 255), faithful=True)
+        want_conn[i] = float(r["ok"] and not r["hit"] and not (r["unknown"] > 6.1 / w.resolution * 0.3))
+    np.testing.assert_array_equal(got[:, 9], want_conn)
+    assert 0 < want_conn.sum() < n

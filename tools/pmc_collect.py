@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Collects the counter evidence behind bench.py's `roofline` object on the GPU box and writes profiles-ready summaries.
+
+    python3 tools/pmc_collect.py [--out gpurun_out/pmc_r02] [--workload C3] [--skip-calib]
+
+This driver never touches the GPU itself (no torch, no HIP): every measurement is a child `rocprofv3 ... -- python3 bench.py`
+(or `-- tools/valu_calib`), one PMC pass per counter set as MI355X_MICROARCH.md "rocprofv3 PMC slots" prescribes (8 SQ
+slots, FETCH_SIZE and WRITE_SIZE in passes of their own), never combined with a trace domain other than --kernel-trace.
+Outputs (under --out):
+    kernel_stats.csv            rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0`
+    pmc_<pass>.csv              per-dispatch counter rows of our kernels
+    calib_stdout.jsonl          tools/valu_calib's own s_memtime measurement
+    pmc_calib_<pass>.csv        the calibration kernels through the same counters
+    pmc_summary.json            what bench.py replays (keyed by the kernel sources' hash): copy to profiles/pmc_summary.json
+"""
+from __future__ import annotations
+
+import argparse
+import collections
+import csv
+import glob
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SQ_PASSES = {
+    "insts": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_FLAT"],
+    "cycles": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"],
+    "stalls": ["SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_THREAD_CYCLES_VALU", "SQ_INST_CYCLES_VMEM"],
+    "grbm": ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
+    "fetch": ["FETCH_SIZE"],
+    "write": ["WRITE_SIZE"],
+    "tcc": ["TCC_HIT_sum", "TCC_MISS_sum"],
+}
+CALIB_PASSES = {
+    "insts": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU"],
+    "cycles": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"],
+    "grbm": ["GRBM_GUI_ACTIVE"],
+}
+
+
+def source_hash() -> str:
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "fit-slam_amd", "csrc")
+    for f in sorted(x for x in os.listdir(csrc) if x.endswith((".hip", ".h"))):
+        h.update(f.encode())
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "fitslam_frontier.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def available_counters(out: str) -> set:
+    path = os.path.join(out, "counters_available.txt")
+    if not os.path.exists(path):
+        r = subprocess.run(["rocprofv3", "-L"], capture_output=True, text=True, timeout=300, cwd="/tmp")
+        open(path, "w").write(r.stdout + r.stderr)
+    text = open(path).read()
+    return set(re.findall(r"\b([A-Z][A-Za-z0-9_]{3,})\b", text))
+
+
+def run(cmd, log, timeout):
+    t0 = time.time()
+    print(f"[pmc] {' '.join(cmd)}", flush=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    with open(log, "w") as f:
+        try:
+            r = subprocess.run(cmd, stdout=f, stderr=subprocess.STDOUT, timeout=timeout, cwd="/tmp", env=env)
+            rc = r.returncode
+        except subprocess.TimeoutExpired:
+            print(f"[pmc] TIMEOUT after {timeout} s: stopping (no further GPU step after a hang)", flush=True)
+            raise SystemExit(5)
+    print(f"[pmc]   -> rc {rc} in {time.time() - t0:.0f} s", flush=True)
+    return rc
+
+
+def kernel_key(name: str) -> str:
+    m = re.search(r"(fs_\w+|valu_stream)(<\d+)?", name)
+    return m.group(0) if m else name[:60]
+
+
+def collect_rows(d: str, dst_csv: str, keep=("fs_", "valu_stream")):
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        rows += [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in keep)]
+    if rows:
+        fields = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count",
+                  "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+        with open(dst_csv, "w", newline="") as o:
+            w = csv.DictWriter(o, fieldnames=fields, extrasaction="ignore")
+            w.writeheader()
+            w.writerows(rows)
+    return rows
+
+
+def averages(rows, last=6):
+    """kernel -> counter -> mean over the last `last` dispatches (the timed steps; earlier ones include warm-up)."""
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        d[kernel_key(r["Kernel_Name"])][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]),
+                                                                   int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out = {}
+    for k, cs in d.items():
+        out[k] = {}
+        for c, vals in cs.items():
+            vals = sorted(vals)[-last:]
+            out[k][c] = sum(v[1] for v in vals) / len(vals)
+            out[k]["_duration_ns"] = sum(v[2] for v in vals) / len(vals)
+            out[k]["_dispatches"] = len(cs[c])
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc_r02"))
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--depth-cells", type=int, default=0)
+    ap.add_argument("--skip-calib", action="store_true")
+    ap.add_argument("--skip-stats", action="store_true")
+    ap.add_argument("--passes", default=",".join(SQ_PASSES))
+    args = ap.parse_args()
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    have = available_counters(out)
+    bench = ["python3", os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--cpu-seconds", "0", "--no-parity"]
+    if args.depth_cells:
+        bench += ["--depth-cells", str(args.depth_cells)]
+    summary = {"source_hash": source_hash(), "workload": args.workload, "depth_cells": args.depth_cells,
+               "collected_with": "tools/pmc_collect.py: rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- "
+                                 "python3 bench.py --steps 3 --warmup 2 --repeats 2 --cpu-seconds 0 --no-parity; means over the last 6 dispatches",
+               "counters_missing": []}
+
+    if not args.skip_stats:
+        d = os.path.join(out, "stats")
+        shutil.rmtree(d, ignore_errors=True)
+        run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", *bench, "--steps", "20", "--warmup", "5", "--repeats", "5"],
+            os.path.join(out, "stats.log"), 600)
+        for f in glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(out, "kernel_stats.csv"))
+        bl = [ln for ln in open(os.path.join(out, "stats.log")) if ln.startswith("{") and '"metric"' in ln]
+        if bl:
+            open(os.path.join(out, "bench_under_rocprof.json"), "w").write(bl[-1])
+
+    per_kernel = collections.defaultdict(dict)
+    for name in args.passes.split(","):
+        ctrs = [c for c in SQ_PASSES[name] if c in have]
+        summary["counters_missing"] += [c for c in SQ_PASSES[name] if c not in have]
+        if not ctrs:
+            continue
+        d = os.path.join(out, f"pass_{name}")
+        shutil.rmtree(d, ignore_errors=True)
+        rc = run(["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", *bench, "--steps", "3", "--warmup", "2", "--repeats", "2"],
+                 os.path.join(out, f"pass_{name}.log"), 600)
+        if rc != 0:
+            summary.setdefault("failed_passes", []).append(name)
+            continue
+        rows = collect_rows(d, os.path.join(out, f"pmc_{name}.csv"))
+        for k, v in averages(rows).items():
+            per_kernel[k].update(v)
+        shutil.rmtree(d, ignore_errors=True)
+
+    calib = {}
+    exe = os.path.join(ROOT, "tools", "valu_calib")
+    if not args.skip_calib and os.path.exists(exe):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        open(os.path.join(out, "calib_stdout.jsonl"), "w").write(r.stdout + r.stderr)
+        calib["s_memtime"] = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{\"waves")]
+        ck = collections.defaultdict(dict)
+        for name, ctrs in CALIB_PASSES.items():
+            ctrs = [c for c in ctrs if c in have]
+            d = os.path.join(out, f"calib_{name}")
+            shutil.rmtree(d, ignore_errors=True)
+            rc = run(["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", exe], os.path.join(out, f"calib_{name}.log"), 300)
+            if rc == 0:
+                rows = collect_rows(d, os.path.join(out, f"pmc_calib_{name}.csv"))
+                for k, v in averages(rows, last=1).items():      # the second (timed) launch of each configuration
+                    ck[k].update(v)
+            shutil.rmtree(d, ignore_errors=True)
+        calib["counters"] = ck
+
+    # ---- derived figures
+    summary["kernels"] = per_kernel
+    summary["calibration"] = calib
+    # peak VALU issue rate of one SIMD, wave-instructions per cycle: from the calibration kernel's own s_memtime (W >= 2)
+    peak = None
+    if calib.get("s_memtime"):
+        best = min(c["simd_cycles_per_wave_inst"] for c in calib["s_memtime"])
+        peak = 1.0 / best
+        summary["valu_peak_wave_insts_per_cycle_per_simd"] = peak
+        summary["valu_simd_cycles_per_wave_inst"] = {str(c["waves_per_simd"]): c["simd_cycles_per_wave_inst"] for c in calib["s_memtime"]}
+    fim = next((v for k, v in per_kernel.items() if k.startswith("fs_fim_kernel")), None)
+    if fim:
+        n_simd = 256 * 4
+        cyc = fim.get("GRBM_GUI_ACTIVE", 0) / 8.0                      # rocprofv3 sums the 8 XCDs
+        res = {"duration_us": fim.get("_duration_ns", 0) / 1e3, "gpu_cycles": cyc}
+        if cyc and "SQ_INSTS_VALU" in fim:
+            res["valu_wave_insts_per_cycle_per_simd"] = fim["SQ_INSTS_VALU"] / (n_simd * cyc)
+            if peak:
+                res["valu_issue_utilisation"] = res["valu_wave_insts_per_cycle_per_simd"] / peak
+                summary["valu_issue_utilisation"] = res["valu_issue_utilisation"]
+        if cyc and "SQ_INSTS_SALU" in fim:
+            res["salu_insts_per_cycle_per_cu"] = fim["SQ_INSTS_SALU"] / (256 * cyc)
+        wc = fim.get("SQ_WAVE_CYCLES")
+        if wc:
+            for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS",
+                      "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_INST_CYCLES_SALU"):
+                if c in fim:
+                    res[f"{c}_share_of_wave_cycles"] = fim[c] / wc
+        if "FETCH_SIZE" in fim or "WRITE_SIZE" in fim:
+            f_kib, w_kib = fim.get("FETCH_SIZE", 0.0), fim.get("WRITE_SIZE", 0.0)
+            # gfx950: FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read (MI355X_MICROARCH.md, HBM): doubled
+            summary["fs_fim_kernel_hbm_bytes_per_launch"] = int((2 * f_kib + w_kib) * 1024)
+            summary["fs_fim_kernel_hbm_bytes_per_launch_uncorrected"] = int((f_kib + w_kib) * 1024)
+        if "TCC_HIT_sum" in fim:
+            res["l2_hit_rate"] = fim["TCC_HIT_sum"] / max(1.0, fim["TCC_HIT_sum"] + fim.get("TCC_MISS_sum", 0.0))
+        summary["fs_fim_kernel"] = res
+    json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True, default=dict)
+    print(json.dumps({k: summary.get(k) for k in ("source_hash", "valu_peak_wave_insts_per_cycle_per_simd", "valu_issue_utilisation", "fs_fim_kernel",
+                                                 "fs_fim_kernel_hbm_bytes_per_launch", "counters_missing", "failed_passes")}, indent=1, default=dict))
+
+
+if __name__ == "__main__":
+    main()

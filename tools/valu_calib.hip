@@ -1,0 +1,83 @@
+// valu_calib.hip — what does the vector ALU of one gfx950 SIMD sustain, and what do the SQ counters read when it does?
+//
+// Settles the normalisation of "VALU utilisation" (VERDICT r01, weak #4): a stream of INDEPENDENT v_fma_f32 is issued
+// by W waves per SIMD (W = 1, 2, 4, 8) on every SIMD of the chip; each wave stamps s_memtime around its loop, so the
+// cycles one wave-instruction holds the SIMD for are read directly (and the same launch under
+// `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES` / `GRBM_GUI_ACTIVE` shows what those
+// counters saturate at).  Expected from MI355X_MICROARCH.md:53-54,473: SIMD-32, 2 cycles per wave64 instruction with
+// >= 2 waves interleaved, 4 for one wave alone.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/valu_calib tools/valu_calib.hip && ./tools/valu_calib
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int kUnroll = 16;      // independent accumulators: no dependency stall at any issue rate
+constexpr int kIters = 4096;     // 65,536 v_fma_f32 per wave
+
+// 256-thread workgroups = one wave per SIMD; W workgroups per CU give W waves per SIMD (round-robin dispatch)
+template <int W>
+__global__ __launch_bounds__(256) void valu_stream(float *out, unsigned long long *cycles, float a, float b)
+{
+    float acc[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) acc[u] = (float)(threadIdx.x + u);
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
+    for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(b));
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) s += acc[u];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int W>
+int run(int cus, float *d_out, unsigned long long *d_cyc)
+{
+    const int blocks = cus * W;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(valu_stream<W>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 1.0001f, 0.5f);   // warm-up
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(valu_stream<W>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 1.0001f, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> cyc((size_t)blocks * 4);
+    CHECK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+    std::sort(cyc.begin(), cyc.end());
+    const double med = (double)cyc[cyc.size() / 2];
+    const double insts = (double)kUnroll * kIters;
+    // a wave gets 1/W of its SIMD: cycles the SIMD spends per wave-instruction = wave's cycles per instruction / W
+    std::printf("{\"waves_per_simd\": %d, \"blocks\": %d, \"wave_insts\": %.0f, \"median_wave_cycles\": %.0f, "
+                "\"cycles_per_inst_per_wave\": %.3f, \"simd_cycles_per_wave_inst\": %.3f, \"kernel_ms\": %.4f, "
+                "\"chip_wave_insts_per_us\": %.1f}\n",
+                W, blocks, insts, med, med / insts, med / insts / W, ms, (double)blocks * 4 * insts / (ms * 1e3));
+    return 0;
+}
+
+int main()
+{
+    int cus = 0;
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    float *d_out; unsigned long long *d_cyc;
+    CHECK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * sizeof(float)));
+    CHECK(hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * sizeof(unsigned long long)));
+    std::printf("{\"cus\": %d, \"s_memtime\": \"shader cycles\"}\n", cus);
+    if (run<1>(cus, d_out, d_cyc)) return 1;
+    if (run<2>(cus, d_out, d_cyc)) return 1;
+    if (run<4>(cus, d_out, d_cyc)) return 1;
+    if (run<8>(cus, d_out, d_cyc)) return 1;
+    return 0;
+}
