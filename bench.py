@@ -347,7 +347,7 @@ def run_rank(args) -> int:
     ovf_ms, ovf_n = sc.kernel_time(2)
     sort_ms, sort_n = sc.kernel_time(4)
     m_tested = sc.get_counter(0, reset=True) / max(1, n_steps_all * n_local)   # landmark tests per candidate on this rank
-    tier2, tier3 = sc.get_counter(4), sc.get_counter(5)
+    multipass, tier3 = sc.get_counter(4), sc.get_counter(5)
     sc.enable_kernel_timing(False)
 
     if world > 1:
@@ -390,7 +390,7 @@ def run_rank(args) -> int:
             "bruteforce_bytes_per_candidate": m * 12 + 32,
             "candidates_per_launch": n_local / max(launches_per_step, 1e-9), "launches_per_step": launches_per_step,
             "avg_launch_ms": fim_ms / max(fim_n, 1), "launches": fim_n,
-            "hash_tier2_candidates": tier2, "hash_tier3_candidates": tier3,
+            "multi_pass_candidates": multipass, "hbm_table_candidates": tier3,
             "whole_step_frac": (n_local * (b_fim + b_ray) / (dt / args.steps)) / 1e9 / HBM_PEAK_GBS,
             "counters": ({k: prof[k] for k in ("source_hash", "valu_issue_utilisation", "valu_peak_wave_insts_per_cycle_per_simd",
                                                 "fs_fim_kernel", "collected_with") if k in prof} if prof else None),

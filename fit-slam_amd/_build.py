@@ -23,9 +23,11 @@ RESOURCES = os.path.join(CSRC, "kernel_resources.json")
 # The FIM workers run two 512-thread (or one 1024-thread) workgroups per CU = 4 waves per SIMD: more than 128 VGPRs
 # halves the occupancy, and a spill lands in the innermost loop.  The register allocation of these kernels has flipped
 # on innocent-looking edits, so the build checks it.
-RESOURCE_LIMITS = {"fs_fim_kernel": (128, 0), "fs_fim_tier2_kernel": (128, 0)}
+RESOURCE_LIMITS = {"fs_fim_kernel": (128, 0)}
 if os.environ.get("FS_BOUNDS"):           # development: range-checked global accesses in the FIM (counter 30) and ray (29) kernels
     HIPCC_FLAGS += ["-DFS_FIM_BOUNDS", "-DFS_RAY_BOUNDS"]
+if os.environ.get("FS_FIM_ABLATE"):       # development: timing-only ablations of the FIM worker (wrong results; see fs_fim.hip)
+    HIPCC_FLAGS.append("-DFS_FIM_ABLATE=" + os.environ["FS_FIM_ABLATE"])
 if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counters of the FIM worker in counters 16..24
     HIPCC_FLAGS.append("-DFS_FIM_STAMPS")
 

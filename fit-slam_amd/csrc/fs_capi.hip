@@ -77,7 +77,7 @@ struct fs_ctx {
     DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
     bool opt_cull = true;
     int opt_bits1 = 14;            // development knobs (fs_set_option "fim.bits1", "fim.skip32")
-    int opt_skip32 = 12;
+    int opt_skip32 = 13;
     DevBuf<unsigned long long> d_counters;
 
     // lookup table
@@ -440,15 +440,11 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
         a.sin_a = (float)std::sin(c->fp.max_angle + 1.0e-3);
         if (c->fp.max_angle + 1.0e-3 >= M_PI / 2) a.cone_mode = (a.cone_mode == 1) ? 3 : 2;   // 3: exact predicate of mode 1, no cone culling
     }
-    // tier 1: 2^14 LDS slots (64 KiB, two 512-thread workgroups per CU) or fewer for small clouds;
-    // tier 2: 2^15 slots (128 KiB, one 1024-thread workgroup per CU); tier 3: HBM
+    // LDS tier: 2^14 slots (64 KiB, two 512-thread workgroups per CU) or fewer for small clouds; crowded poses are
+    // scored in passes; the HBM tier behind it takes what still overflows
     int bits = 10;
     while (bits < c->opt_bits1 && (1 << bits) < 2 * c->m) ++bits;
     a.hash_bits = bits;
-    a.hash_bits2 = ((1 << bits) < 2 * c->m) ? 15 : bits;
-    // very large clouds: the tier's chunk masks no longer fit next to its 128-KiB table -> HBM tier directly
-    if (a.hash_bits2 > bits && fs_fim_tier2_lds_bytes(a.hash_bits2, c->n_chunks) > 160 * 1024) a.hash_bits2 = bits;
-    a.fail_code1 = (a.hash_bits2 > a.hash_bits) ? 1u : 2u;
     a.skip32 = c->opt_skip32;
     a.gtable = c->d_gtable.p;
     a.ghash_bits = c->ghash_bits;

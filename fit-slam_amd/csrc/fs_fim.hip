@@ -25,9 +25,9 @@
 //               sequential loop.  Unit-weight 6x6 FIM via the block form [[P/n^2,-S/n^2],[S/n^2,P]].
 //   5. reduce — wave shuffles, LDS across waves, fp64 per quantity; fs_fim_finish_kernel assembles F,
 //               trace and the Cholesky log det.
-// Hash tables are tiered: 2^14 LDS slots per 512-thread workgroup (two workgroups per CU); candidates
-// with more distinct voxels are flagged and re-scored with 2^15 slots / 1024 threads, then with a table
-// in HBM.  Scan + scatter-count has no dense contraction: no MFMA.
+// Hash tables: 2^14 LDS slots per 512-thread workgroup (two workgroups per CU).  A candidate predicted to hold more
+// distinct voxels than the table takes is scored by the same workgroup in 2, 4 or 8 voxel-partitioned PASSES; only a
+// real overflow hands it to the table in HBM.  Scan + scatter-count has no dense contraction: no MFMA.
 #include "fs_internal.h"
 
 #define FS_NACC 18       // info, 15 FIM block sums, n_visible, n_voxels
@@ -39,6 +39,12 @@
 #define FS_STAMP(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); st[k] += now_ - tprev; tprev = now_; } while (0)
 #else
 #define FS_STAMP(k) do { } while (0)
+#endif
+
+// development: timing-only ablations of the worker (results are WRONG; bench with --no-parity).  FS_FIM_ABLATE = 1: no
+// hash-table work in a score call (block sums only); 2: no score calls at all; 3: no landmark tests either (cull only).
+#ifndef FS_FIM_ABLATE
+#define FS_FIM_ABLATE 0
 #endif
 
 #define FS_T1_THREADS 512
@@ -119,6 +125,9 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
                                               bool active, float px, float py, float pz, Acc &acc, bool &overflow)
 {
     acc.nvis += active ? 1 : 0;
+#if FS_FIM_ABLATE >= 2
+    return false;
+#endif
     bool in_table;
     const uint32_t key = voxel_key(a, active, px, py, pz, in_table);
     // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
@@ -154,6 +163,9 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     uint32_t rank = 0u;
     bool is_new = false;
     bool done = !valid;
+#if FS_FIM_ABLATE == 1
+    done = true; rank = 1u;
+#endif
     for (uint32_t probe = 0; probe < max_probe; ++probe) {
         if (probe != 0u) {
             if (__all(done)) break;                                       // second round trips are rare
@@ -239,18 +251,20 @@ struct FimWork {
 // finished its share of candidate i culls the chunks of candidate i+1 before it joins the reduction barrier, so the
 // latency of the sphere loads and the imbalance between waves overlap instead of adding up.  Two barriers per
 // candidate: after the table clear and after the reduction.
-// FAIL_CODE: the tier a failed candidate is handed to (1: the second LDS tier, 2: the HBM tier, 3: nobody) — a
-// template parameter so that each tier only carries the code of its own hand-over rule.
-template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, uint32_t FAIL_CODE>
+// A candidate the LDS worker cannot finish (GLOBAL_TABLE false) is appended to the work list of the HBM tier; the HBM
+// worker itself (GLOBAL_TABLE true) has nobody to hand over to and only counts such a candidate (never observed).
+// CONE1: the visibility cone is the common one (half-angle < pi/2, FsFimArgs::cone_mode == 1) — a template parameter so
+// that the test loop carries one predicate instead of a scalar dispatch over the four modes per chunk.
+template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, bool CONE1>
 __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits)
 {
-    constexpr uint32_t fail_code = FAIL_CODE;
+    constexpr uint32_t fail_code = GLOBAL_TABLE ? 3u : 2u;
     constexpr int WAVES = THREADS / 64;
     constexpr int STRIDE = WAVES * 64;
     const uint32_t max_probe = GLOBAL_TABLE ? (1u << tier_bits) : FS_MAX_PROBE;   // bucket visits incl. re-reads
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    __shared__ int sh_overflow[2], sh_nvox[2], sh_wave_tested[2][WAVES], sh_next[2];
+    __shared__ int sh_overflow[2], sh_wave_tested[2][WAVES], sh_next[2];
     __shared__ float sh_red[WAVES * FS_NACC];
 
     const float4 *__restrict__ spheres = reinterpret_cast<const float4 *>(a.spheres);
@@ -287,7 +301,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const float d2 = dx * dx + dy * dy + dz * dz;
                 const float reach = a.max_dist_f + s.w;
                 keep = reach >= 0.0f && d2 <= reach * reach;         // empty chunks carry a hugely negative radius
-                if (keep && a.cone_mode == 1 && d2 > s.w * s.w) {
+                if (keep && (CONE1 || a.cone_mode == 1) && d2 > s.w * s.w) {
                     // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
                     // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one
                     // hardware square root; the margin dwarfs its 1-ulp error)
@@ -326,7 +340,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     if (tid == 0) {
         const int first = fetch();
         sh_next[0] = first; sh_next[1] = first >= 0 ? fetch() : -1;
-        sh_overflow[0] = 0; sh_overflow[1] = 0; sh_nvox[0] = 0; sh_nvox[1] = 0;
+        sh_overflow[0] = 0; sh_overflow[1] = 0;
     }
     for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
     __syncthreads();
@@ -356,21 +370,19 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
         // candidates clear only a small table.  The running voxel count in the main loop is the exact safety net.
         //
-        // The first tier hands a candidate predicted to overfill its table to the second one (a failed attempt would be
-        // wasted work, and heavy candidates at the end of this kernel would be its tail).  The second tier — the last
-        // one with an LDS table — scores a candidate that is too big even for its table in n_parts PASSES over the
-        // accepted chunks: every pass re-tests the landmarks but only queues those whose voxel belongs to the pass
-        // (voxel_part), so each landmark is still scored exactly once and each pass needs 1/n_parts of the table.
-        // That costs one extra test per landmark and pass, against a table in HBM with two dependent global atomics
-        // per landmark (measured on C5: 3x faster per candidate).
+        // A candidate predicted to overfill the table is scored in n_parts PASSES over its accepted chunks: every pass
+        // re-tests the landmarks but only queues those whose voxel belongs to the pass (voxel_part), so each landmark is
+        // still scored exactly once and each pass needs 1/n_parts of the table.  That costs one extra test per landmark
+        // and pass, against a table in HBM with two dependent global atomics per landmark (measured on C5: 3x faster per
+        // candidate) or a hand-over to a second kernel with a larger LDS table (round 1: a 0.18 ms serial tail on C3).
+        // Prediction: distinct voxels <= skip32/32 of the landmarks scanned (measured p99 0.40 on C3; 13/32 by default);
+        // a candidate that overflows a pass all the same is handed to the HBM tier — correct, just slower.
         const long long capacity = 3ll << (tier_bits - 2);                           // 3/4 of the largest table
         int n_parts = 1;
         bool skip_tier = false;
-        if (!GLOBAL_TABLE && fail_code == 1u) {
-            skip_tier = (long long)wg_tested * 64 * a.skip32 > capacity * 32;
-        } else if (!GLOBAL_TABLE) {
-            const long long worst = (long long)wg_tested * 32;                        // distinct voxels <= 0.5 of the landmarks scanned
-            while (n_parts <= FS_MAX_PARTS && worst > capacity * n_parts) n_parts <<= 1;
+        if (!GLOBAL_TABLE) {
+            const long long predicted = (long long)wg_tested * 2 * a.skip32;           // = landmarks scanned * skip32 / 32
+            while (n_parts <= FS_MAX_PARTS && predicted > capacity * n_parts) n_parts <<= 1;
             skip_tier = n_parts > FS_MAX_PARTS;                                       // hopeless here: HBM tier
         }
         int bits = tier_bits;
@@ -380,7 +392,6 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             bits = need;
         }
         const uint32_t slots = 1u << bits;
-        const int nvox_limit = GLOBAL_TABLE ? 0x7fffffff : (int)((slots >> 2) * 3u);
         if (!skip_tier && wg_tested > 0) {
             if (GLOBAL_TABLE) {
                 for (uint32_t i = tid; i < slots; i += THREADS) table[i] = 0u;
@@ -399,9 +410,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         __syncthreads();                                           // table cleared
         FS_STAMP(1);
         const int nxt = sh_next[buf ^ 1];
-        if (tid == 0) { sh_overflow[buf ^ 1] = 0; sh_nvox[buf ^ 1] = 0; }   // flags of the candidate after this one
+        if (tid == 0) sh_overflow[buf ^ 1] = 0;                    // flag of the candidate after this one
         volatile int *v_overflow = &sh_overflow[buf];
-        volatile int *v_nvox = &sh_nvox[buf];
         bool overflow = false;
         if (skip_tier) { overflow = true; if (tid == 0) *v_overflow = 1; }
 
@@ -421,7 +431,6 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             const bool stop = *v_overflow != 0;                    // uniform: nobody writes the flag between these barriers
             uint4 *t4 = reinterpret_cast<uint4 *>(table);
             for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (tid == 0) sh_nvox[buf] = 0;
             __syncthreads();
             if (stop) break;                                       // an earlier pass ran out of table: next tier
         }
@@ -432,19 +441,16 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             unsigned long long mask = masks[g];
             mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
-            if (!GLOBAL_TABLE) {
-                if (*v_overflow) break;                            // another wave ran out of table: the next tier redoes it
-                // First tier only: distinct voxels so far, extrapolated over the chunks still to come — a table that
-                // clearly will not fit is handed on early.  (The last LDS tier sizes its passes for the worst case and
-                // only stops on a real overflow: a false alarm there would cost a pass through the HBM tier.)
-                if (fail_code == 1u && g > 0 && (long long)(*v_nvox) * a.n_chunks > (long long)nvox_limit * g0 * 5 / 4) { overflow = true; *v_overflow = 1; break; }
-            }
+            if (!GLOBAL_TABLE && *v_overflow) break;                // another wave ran out of table: the HBM tier redoes it
             auto pop = [&]() -> int {
                 if (!mask) return -1;
                 const int id = g0 + __builtin_ctzll(mask) * WAVES + wave;
                 mask &= mask - 1ull;
                 return id;
             };
+#if FS_FIM_ABLATE >= 3
+            mask = 0ull;
+#endif
             int c0 = pop(), c1 = pop();
             float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
             if (c0 >= 0 && FS_BOUND(c0 < a.n_chunks, 3)) { const uint32_t l = (uint32_t)(c0 * 64 + lane); x0 = ldg32(LX, l); y0 = ldg32(LY, l); z0 = ldg32(LZ, l); }
@@ -460,7 +466,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
                 const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
                 bool vis = (n2 <= a.maxd2);
-                if (a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
+                if (CONE1 || a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
                 else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px * px <= a.cos2 * n2));
                 if (n_parts > 1) vis = vis && voxel_part(a, vis, px, n_parts) == part;   // wave-uniform branch
                 // ---- 3. compact
@@ -482,10 +488,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #ifdef FS_FIM_STAMPS
                         st[8] += __builtin_readcyclecounter() - ts_; st[9] += 1;
 #endif
-                        const unsigned long long om = __ballot(opened);
-                        // running count of distinct voxels for the checks at the top of every cull pass (fire and forget:
-                        // nothing here waits for the LDS; a table that really fills up fails its probe limit first)
-                        if (!GLOBAL_TABLE && om != 0ull && lane == 0) atomicAdd(&sh_nvox[buf], (int)__popcll(om));
+                        (void)opened;
                         if (__any(overflow)) *v_overflow = 1;
                     }
                 }
@@ -536,11 +539,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + tid] = x;
         }
         if (tid == 0) {
-            a.overflow[c] = failed ? fail_code : 0u;                  // the next tier re-scores flagged candidates
+            a.overflow[c] = failed ? fail_code : 0u;                  // the HBM tier re-scores flagged candidates
             if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);   // landmarks tested (M_tested), summed by the finish kernel
-            if (failed && fail_code < 3u) {
-                const unsigned long long slot = atomicAdd(&a.counters[fail_code], 1ull);
-                if (FS_BOUND(slot < (unsigned long long)a.n, 4)) a.flagged[(size_t)(fail_code - 1u) * a.n + slot] = c;          // work list of the next tier
+            if (!GLOBAL_TABLE && n_parts > 1 && !failed) atomicAdd(&a.counters[1], 1ull);   // scored in several passes
+            if (failed && !GLOBAL_TABLE) {
+                const unsigned long long slot = atomicAdd(&a.counters[2], 1ull);
+                if (FS_BOUND(slot < (unsigned long long)a.n, 4)) a.flagged[slot] = c;          // work list of the HBM tier
             } else if (failed) {
                 atomicAdd(&a.counters[3], 1ull);
             }
@@ -550,43 +554,34 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         FS_STAMP(7);
     }
 #ifdef FS_FIM_STAMPS
-    if (lane == 0 && !GLOBAL_TABLE && fail_code == a.fail_code1 && THREADS == FS_T1_THREADS) {
+    if (lane == 0 && !GLOBAL_TABLE && THREADS == FS_T1_THREADS) {
         for (int k = 0; k < 10; ++k) atomicAdd(&a.counters[16 + k], st[k]);
         atomicAdd(&a.counters[31], 1ull);
     }
 #endif
 }
 
-// tier 1: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
+// LDS tier: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
 // (two workgroups of 8 waves per CU = 4 waves per SIMD: the register allocator must stay within 128 VGPRs)
-template <int THREADS, bool TABLE_FULL, uint32_t FAIL_CODE>
+template <int THREADS, bool TABLE_FULL, bool CONE1>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4)))
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
-    fim_worker<THREADS, false, TABLE_FULL, FAIL_CODE>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits);
+    fim_worker<THREADS, false, TABLE_FULL, CONE1>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits);
 }
 
-// tier 2: candidates tier 1 appended to its work list, with a larger LDS table
-template <int THREADS, bool TABLE_FULL>
-__global__ __launch_bounds__(THREADS)
-void fs_fim_tier2_kernel(const FsFimArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    const FimWork work{a.flagged, 0, (int)a.counters[1], a.counters + 7};
-    fim_worker<THREADS, false, TABLE_FULL, 2u>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits2);
-}
-
-// tier 3: candidates on the second work list; table in HBM with 2x the landmark count of slots and unbounded probing
+// HBM tier: candidates the LDS tier appended to its work list; table in HBM with 2x the landmark count of slots and
+// unbounded probing
 template <int THREADS, bool TABLE_FULL>
 __global__ __launch_bounds__(THREADS)
 void fs_fim_tier3_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    const FimWork work{a.flagged + a.n, 0, (int)a.counters[2], a.counters + 9};
+    const FimWork work{a.flagged, 0, (int)a.counters[2], a.counters + 9};
     uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
-    fim_worker<THREADS, true, TABLE_FULL, 3u>(a, work, fs_fim_lds, table, a.ghash_bits);
+    fim_worker<THREADS, true, TABLE_FULL, false>(a, work, fs_fim_lds, table, a.ghash_bits);
 }
 
 // One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
@@ -709,19 +704,13 @@ hipError_t allow_lds(K kernel, size_t bytes)
 }  // namespace
 
 
-size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks)
-{
-    int groups = 0;
-    return lds_bytes<FS_T2_THREADS>(hash_bits2, false, n_chunks, &groups) + 2048;   // + the worker's static arrays, rounded up
-}
-
 namespace {
 
-template <bool TABLE_FULL, uint32_t FAIL_CODE>
+template <bool TABLE_FULL, bool CONE1>
 hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
 {
     const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
-    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, FAIL_CODE>;
+    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, CONE1>;
     hipError_t e = allow_lds(kernel, lds);
     if (e != hipSuccess) return e;
     static int resident = 0;                                   // same kernel, same LDS budget class: query once
@@ -734,15 +723,6 @@ hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
 template <bool TABLE_FULL>
 hipError_t launch_overflow(FsFimArgs &a, int pool, hipStream_t s)
 {
-    if (a.hash_bits2 > a.hash_bits) {
-        const size_t lds2 = lds_bytes<FS_T2_THREADS>(a.hash_bits2, false, a.n_chunks, &a.n_groups);
-        auto kernel2 = fs_fim_tier2_kernel<FS_T2_THREADS, TABLE_FULL>;
-        hipError_t e = allow_lds(kernel2, lds2);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kernel2, dim3(a.n < 256 ? a.n : 256), dim3(FS_T2_THREADS), lds2, s, a);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
     const int blocks = a.n < pool ? a.n : pool;
     const size_t lds3 = lds_bytes<FS_T2_THREADS>(0, true, a.n_chunks, &a.n_groups);
     auto kernel3 = fs_fim_tier3_kernel<FS_T2_THREADS, TABLE_FULL>;
@@ -758,8 +738,8 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
     if (a0.n <= 0 || a0.cand_count <= 0) return hipSuccess;
     FsFimArgs a = a0;
-    if (a.fail_code1 == 1u) return a.table_full ? launch_tier1<true, 1u>(a, s) : launch_tier1<false, 1u>(a, s);
-    return a.table_full ? launch_tier1<true, 2u>(a, s) : launch_tier1<false, 2u>(a, s);
+    if (a.cone_mode == 1) return a.table_full ? launch_tier1<true, true>(a, s) : launch_tier1<false, true>(a, s);
+    return a.table_full ? launch_tier1<true, false>(a, s) : launch_tier1<false, false>(a, s);
 }
 
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a0, int pool, hipStream_t s)

@@ -138,19 +138,17 @@ struct FsFimArgs {
     int32_t *n_visible, *n_voxels;
     double *sums;              // [n][18] reduced per-candidate sums (info, 15 FIM block sums, n_visible, n_voxels)
     uint32_t *overflow;        // [n] tier that must re-score the candidate (0 = done)
-    int32_t *flagged;          // [2][n] work lists: candidates tier 1 / tier 2 hand to the next tier
+    int32_t *flagged;          // [n] work list: candidates the LDS tier hands to the HBM tier
     uint32_t *tested;          // [n] landmark tests spent on the candidate (all tiers); zeroed by the finish kernel
     // fused scoring: the finish kernel also assembles the 32-byte records (nullptr: separate outputs only)
     fs_record *records;
     const int32_t *rec_arrival, *rec_argmax;
     const double *rec_yaw;
     const uint8_t *rec_achievable;
-    unsigned long long *counters;   // [16]: 0 landmarks tested, 1..3 per-call tier failures, 4..6 their running totals, 7/8/9 work-list cursors of tier 2/1/3
+    unsigned long long *counters;   // [16]: 0 landmarks tested; per call 1 multi-pass candidates, 2 handed to the HBM tier, 3 unresolved; 4..6 their running totals; 8 / 9 work-list cursors of the LDS / HBM tier
     // hash tables
-    int32_t hash_bits;         // tier 1 (LDS, 512-thread workgroups)
-    int32_t hash_bits2;        // tier 2 (LDS, 1024-thread workgroups); <= hash_bits disables the tier
-    int32_t skip32;            // tier-1 hand-over prediction: distinct voxels <= skip32/32 of the landmarks scanned
-    uint32_t fail_code1;       // what tier 1 flags on failure: 1 (tier 2 exists) or 2 (straight to tier 3)
+    int32_t hash_bits;         // LDS tier (512-thread workgroups)
+    int32_t skip32;            // pass-count prediction: distinct voxels <= skip32/32 of the landmarks scanned
     uint32_t *gtable;          // tier 3: HBM tables [pool][1 << ghash_bits]
     int32_t ghash_bits;
 };
@@ -171,6 +169,5 @@ hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hipStream_t s);
-size_t fs_fim_tier2_lds_bytes(int hash_bits2, int n_chunks);   // dynamic + static LDS of the 1024-thread tier
 
 #endif

@@ -105,7 +105,7 @@ int  fs_synchronize(fs_ctx *ctx);
 
 /* Per-kernel device time.  With timing enabled every kernel launch is bracketed by hipEvents on
  * the context's stream; fs_kernel_time returns and resets the accumulated (ms, launches) of
- * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM larger-table tiers, 3 utility/rank, 4 candidate sort,
+ * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM HBM-table tier, 3 utility/rank, 4 candidate sort,
  * 5 frontier-cell stencil. */
 int  fs_enable_kernel_timing(fs_ctx *ctx, int enable);
 int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
@@ -115,10 +115,12 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * "ray.sort" (default 1): ray-march candidates in Morton order of their goal cell (lists of >= 2048).
  * "ray.layout" (default 0): which copy of the grid the ray walks read — 0 picks by ray length (row-major image below
  * 96 cells, 8x8x2-brick copy from there on), 1 / 2 force the row-major / bricked walk (identical results).
- * "fim.bits1", "fim.skip32": development knobs of the hash-table tiers. */
+ * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
+ * landmarks scanned, in 32nds, that decides the number of scoring passes: DESIGN.md 4.2). */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
 /* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
- * 4/5/6 = candidates re-scored by the second / third hash-table tier / unresolved (always 0). */
+ * 4 = candidates scored in several voxel-partitioned passes, 5 = candidates re-scored with the table in HBM,
+ * 6 = unresolved (always 0). */
 int  fs_get_counter(fs_ctx *ctx, int which, int64_t *value, int reset);
 
 /* ---------------------------------------------------------------- arrival information (ray-cast) */

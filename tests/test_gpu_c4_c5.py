@@ -93,7 +93,7 @@ def test_c5_brick_upload_full_list_properties_and_oracle_sample(fs, oracle, ref_
         assert base.shape[0] == 50_000
         status = fs.capi.record_status(base)
         assert (status == 2).sum() == int(w.blacklisted.sum()) and (status == 0).sum() > 47_000
-        assert base["n_visible"].max() > 5_000                                                    # crowded poses exist (tier 2)
+        assert base["n_visible"].max() > 5_000                                                    # crowded poses exist (several scoring passes)
         # culling off = brute force over all 500 k landmarks; sorting off; both walks of the grid: identical integers
         for key, val, back in (("fim.cull", 0, 1), ("ray.sort", 0, 1), ("ray.layout", 2, 0)):
             s.set_option(key, val)
@@ -117,7 +117,7 @@ def test_c5_brick_upload_full_list_properties_and_oracle_sample(fs, oracle, ref_
         np.testing.assert_array_equal(_int_view(dense), _int_view(base[sub]))
         idx = np.sort(np.random.default_rng(5).choice(50_000, size=320, replace=False))
         _oracle_spot_check(fs, oracle, ref_table, w, base, idx)
-        assert s.get_counter(6) == 0                                                              # nothing left unresolved by the hash tiers
+        assert s.get_counter(4) > 0 and s.get_counter(6) == 0                                     # crowded poses took several passes; nothing unresolved
     finally:
         s.close()
 

@@ -22,7 +22,7 @@ for bits1, skip in [(14, 12), (14, 14), (14, 11), (14, 10), (14, 9), (14, 12)]:
     t2, t3 = sc.get_counter(4, True), sc.get_counter(5, True)
     if ref is None: ref = rec.copy()
     same = all(np.array_equal(ref[f], rec[f]) for f in ("arrival", "argmax", "n_visible", "flags"))
-    print("bits1 %d skip %2d/32: ray %.3f fim %.3f tiers %.3f ms ; tier2 %d tier3 %d ; ints equal %s ; info maxrel %.2e" % (
+    print("bits1 %d skip %2d/32: ray %.3f fim %.3f tiers %.3f ms ; multi-pass %d HBM tier %d ; ints equal %s ; info maxrel %.2e" % (
         bits1, skip, t[0][0] / max(1, t[0][1]), t[1][0] / max(1, t[1][1]), t[2][0] / max(1, t[2][1]), t2, t3, same,
         np.max(np.abs(ref["info_ref"] - rec["info_ref"]) / np.maximum(1, np.abs(ref["info_ref"])))), flush=True)
 nv = ref["n_visible"]; vox = (ref["flags"] >> 16) & 0xFFFF
