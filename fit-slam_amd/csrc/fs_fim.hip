@@ -47,7 +47,10 @@
 #define FS_FIM_ABLATE 0
 #endif
 
+#ifndef FS_T1_THREADS
 #define FS_T1_THREADS 512
+#endif
+#define FS_T1_WAVES_PER_EU ((FS_T1_THREADS * 2 + 255) / 256)      // two workgroups per CU, four SIMDs
 #define FS_T2_THREADS 1024
 
 #ifdef FS_FIM_BOUNDS   // development: every global access is range-checked, violations are recorded in counters[30] and skipped
@@ -263,7 +266,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     constexpr int STRIDE = WAVES * 64;
     const uint32_t max_probe = GLOBAL_TABLE ? (1u << tier_bits) : FS_MAX_PROBE;   // bucket visits incl. re-reads
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    // the wave index is uniform by construction; telling the compiler so (readfirstlane) keeps chunk ids, queue counts,
+    // loop conditions and address bases in scalar registers instead of exec-masked vector code
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __shared__ int sh_overflow[2], sh_wave_tested[2][WAVES], sh_next[2];
     __shared__ float sh_red[WAVES * FS_NACC];
 
@@ -344,7 +349,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     }
     for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
     __syncthreads();
-    int cur = sh_next[0];
+    // values read back from LDS flags are the same in every lane; readfirstlane tells the compiler so, which keeps the
+    // whole persistent loop's control flow scalar (no exec-mask loops, loop-carried counters in SGPRs)
+    int cur = __builtin_amdgcn_readfirstlane(sh_next[0]);
     int buf = 0;
     float Rn[9], tn[3];
 #pragma unroll
@@ -365,6 +372,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         int wg_tested = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) wg_tested += sh_wave_tested[buf][w];
+        wg_tested = __builtin_amdgcn_readfirstlane(wg_tested);
 
         // ---- size and clear the hash table.  Distinct voxels are at most ~0.5 of the landmarks scanned (measured
         // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
@@ -409,7 +417,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         FS_STAMP(0);
         __syncthreads();                                           // table cleared
         FS_STAMP(1);
-        const int nxt = sh_next[buf ^ 1];
+        const int nxt = __builtin_amdgcn_readfirstlane(sh_next[buf ^ 1]);
         if (tid == 0) sh_overflow[buf ^ 1] = 0;                    // flag of the candidate after this one
         volatile int *v_overflow = &sh_overflow[buf];
         bool overflow = false;
@@ -428,7 +436,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (part > 0) {
             // next pass: everybody is done with the table -> clear it, restart the running voxel count
             __syncthreads();
-            const bool stop = *v_overflow != 0;                    // uniform: nobody writes the flag between these barriers
+            const bool stop = __builtin_amdgcn_readfirstlane(*v_overflow) != 0;   // uniform: nobody writes the flag between these barriers
             uint4 *t4 = reinterpret_cast<uint4 *>(table);
             for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
@@ -441,7 +449,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             unsigned long long mask = masks[g];
             mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
-            if (!GLOBAL_TABLE && *v_overflow) break;                // another wave ran out of table: the HBM tier redoes it
+            if (!GLOBAL_TABLE && __builtin_amdgcn_readfirstlane(*v_overflow)) break;   // another wave ran out of table: the HBM tier redoes it
             auto pop = [&]() -> int {
                 if (!mask) return -1;
                 const int id = g0 + __builtin_ctzll(mask) * WAVES + wave;
@@ -532,7 +540,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         FS_STAMP(6);
         // cross-wave sums in fp64, one thread per quantity; the 6x6 assembly and log det run in
         // fs_fim_finish_kernel so that this kernel carries no private arrays
-        const bool failed = sh_overflow[buf] != 0;
+        const bool failed = __builtin_amdgcn_readfirstlane(sh_overflow[buf]) != 0;
         if (tid < FS_NACC && !failed) {
             double x = 0.0;
             for (int w = 0; w < WAVES; ++w) x += (double)sh_red[w * FS_NACC + tid];
@@ -564,7 +572,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 // LDS tier: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
 // (two workgroups of 8 waves per CU = 4 waves per SIMD: the register allocator must stay within 128 VGPRs)
 template <int THREADS, bool TABLE_FULL, bool CONE1>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4)))
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FS_T1_WAVES_PER_EU)))
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];

@@ -154,7 +154,7 @@ struct FsFimArgs {
 };
 
 #define FS_CHUNK       64       // landmarks per chunk (one wave)
-#define FS_FACTOR_N    512      // exp(1 - k^0.8) underflows to 0.0f for k > ~340
+#define FS_FACTOR_N    352      // (float)exp(1 - k^0.8) is exactly 0.0f from k = 337 on
 #define FS_SLOT_CNT_BITS 11     // slot = (key+1) << 11 | count
 #define FS_SLOT_CNT_MASK ((1u << FS_SLOT_CNT_BITS) - 1u)
 #define FS_SLOT_CNT_SAT  1024u  // counts beyond this contribute exactly 0.0f anyway
