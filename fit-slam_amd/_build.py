@@ -28,6 +28,9 @@ if os.environ.get("FS_BOUNDS"):           # development: range-checked global ac
     HIPCC_FLAGS += ["-DFS_FIM_BOUNDS", "-DFS_RAY_BOUNDS"]
 if os.environ.get("FS_FIM_ABLATE"):       # development: timing-only ablations of the FIM worker (wrong results; see fs_fim.hip)
     HIPCC_FLAGS.append("-DFS_FIM_ABLATE=" + os.environ["FS_FIM_ABLATE"])
+if os.environ.get("FS_T1_WAVES_PER_EU"):  # development: occupancy target of the FIM worker's register allocation
+    HIPCC_FLAGS.append("-DFS_T1_WAVES_PER_EU=" + os.environ["FS_T1_WAVES_PER_EU"])
+    RESOURCE_LIMITS = {}
 if os.environ.get("FS_T1_THREADS"):       # development: workgroup size of the FIM worker (default 512)
     HIPCC_FLAGS.append("-DFS_T1_THREADS=" + os.environ["FS_T1_THREADS"])
 if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counters of the FIM worker in counters 16..24

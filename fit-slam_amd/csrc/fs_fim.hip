@@ -50,7 +50,9 @@
 #ifndef FS_T1_THREADS
 #define FS_T1_THREADS 512
 #endif
+#ifndef FS_T1_WAVES_PER_EU
 #define FS_T1_WAVES_PER_EU ((FS_T1_THREADS * 2 + 255) / 256)      // two workgroups per CU, four SIMDs
+#endif
 #define FS_T2_THREADS 1024
 
 #ifdef FS_FIM_BOUNDS   // development: every global access is range-checked, violations are recorded in counters[30] and skipped
@@ -287,13 +289,32 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass, four
     // sphere loads in flight per lane.  Blacklisted / off-map candidates keep nothing: zero FI.
     // The pose record (R row-major, t) read here is handed to the scoring pass of the same candidate in registers.
-    auto cull = [&](int c, int buf, float *Rn, float *tn) {
-        unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
+    // The pose record and status of a candidate are loaded one iteration before its cull (PoseLoad, issued at the top of
+    // the previous candidate's scoring loop), and the chunk spheres a lane tests are the same for every candidate —
+    // chunk (g * STRIDE + lane * WAVES + wave) for pass g — so the first four passes' spheres stay in registers for the
+    // whole persistent loop: on clouds of up to 4 * THREADS chunks (C3: 1563) a cull issues no load at all.
+    struct PoseLoad { float4 r0, r1, r2; int status; };
+    auto load_pose = [&](int c) -> PoseLoad {
+        PoseLoad p;
         if (!FS_BOUND(c >= 0 && c < a.n, 6)) c = 0;
-        const bool dead = a.status && a.status[c] != FS_STATUS_OK;
-        const float4 r0 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[0];
-        const float4 r1 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[1];
-        const float4 r2 = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c)[2];
+        p.status = a.status ? a.status[c] : FS_STATUS_OK;
+        const float4 *rt = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c);
+        p.r0 = rt[0]; p.r1 = rt[1]; p.r2 = rt[2];
+        return p;
+    };
+    constexpr bool RESIDENT_SPHERES = !GLOBAL_TABLE;              // (the 1024-thread HBM tier has no registers to spare)
+    float4 sp_res[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = u * STRIDE + lane * WAVES + wave;
+        sp_res[u] = (RESIDENT_SPHERES && u < a.n_groups && j < a.n_chunks)
+                        ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
+                        : make_float4(0.f, 0.f, 0.f, -1.f);
+    }
+    auto cull = [&](const PoseLoad &pl, int buf, float *Rn, float *tn) {
+        unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
+        const bool dead = pl.status != FS_STATUS_OK;
+        const float4 r0 = pl.r0, r1 = pl.r1, r2 = pl.r2;
         Rn[0] = r0.x; Rn[1] = r0.y; Rn[2] = r0.z; Rn[3] = r0.w; Rn[4] = r1.x; Rn[5] = r1.y; Rn[6] = r1.z; Rn[7] = r1.w;
         Rn[8] = r2.x; tn[0] = r2.y; tn[1] = r2.z; tn[2] = r2.w;
         const float ax = r0.x, ay = r0.w, az = r1.z;               // the camera's +x axis in the world frame (R[0], R[3], R[6])
@@ -322,9 +343,10 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int j = (gb + u) * STRIDE + lane * WAVES + wave;
-                sp[u] = (gb + u < a.n_groups && j < a.n_chunks)
-                            ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
-                            : make_float4(0.f, 0.f, 0.f, -1.f);
+                if (RESIDENT_SPHERES && gb == 0) sp[u] = sp_res[u];
+                else sp[u] = (gb + u < a.n_groups && j < a.n_chunks)
+                                 ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
+                                 : make_float4(0.f, 0.f, 0.f, -1.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -358,7 +380,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     for (int i = 0; i < 9; ++i) Rn[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) tn[i] = 0.f;
-    if (cur >= 0) cull(cur, 0, Rn, tn);
+    if (cur >= 0) cull(load_pose(cur), 0, Rn, tn);
     __syncthreads();
 
 #ifdef FS_FIM_STAMPS
@@ -418,6 +440,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         __syncthreads();                                           // table cleared
         FS_STAMP(1);
         const int nxt = __builtin_amdgcn_readfirstlane(sh_next[buf ^ 1]);
+        PoseLoad next_pose;                                        // in flight during this candidate's scoring loop
+        if (nxt >= 0) next_pose = load_pose(nxt);
         if (tid == 0) sh_overflow[buf ^ 1] = 0;                    // flag of the candidate after this one
         volatile int *v_overflow = &sh_overflow[buf];
         bool overflow = false;
@@ -517,7 +541,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
         // ---- the next candidate's cull fills the time this wave would otherwise wait for the slower ones
         if (tid == 0) sh_next[buf] = ahead;                        // read by the next iteration after its first barrier
-        if (nxt >= 0) cull(nxt, buf ^ 1, Rn, tn);
+        if (nxt >= 0) cull(next_pose, buf ^ 1, Rn, tn);
 
         FS_STAMP(4);
         // ---- 5. reduce: DPP within the wave, then across waves through LDS
