@@ -1,0 +1,253 @@
+// CostAssignerGPU.cpp — see the header.  Every reference line this file replaces is cited next to the code.
+#include "fitslam_frontier_ros2/CostAssignerGPU.hpp"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+#include <slam_msgs/srv/get_map.hpp>
+
+#include "frontier_exploration/util/logger.hpp"
+
+namespace fitslam_frontier_ros2
+{
+using frontier_exploration::GetFrontierCostsRequest;
+using frontier_exploration::GetFrontierCostsResponse;
+
+CostAssignerGPU::CostAssignerGPU(std::shared_ptr<nav2_costmap_2d::Costmap2DROS> explore_costmap_ros, int device_id)
+{
+    layered_costmap_ = explore_costmap_ros->getLayeredCostmap();                 // CostAssigner.cpp:11
+    costmap_ = explore_costmap_ros->getCostmap();                                // FrontierCostsManager.cpp:19
+    // CostCalculator.cpp:7-9,19
+    max_camera_depth_ = parameterInstance.getValue<double>("costCalculator/max_camera_depth");
+    delta_theta_ = parameterInstance.getValue<double>("costCalculator/delta_theta");
+    camera_fov_ = parameterInstance.getValue<double>("costCalculator/camera_fov");
+    robot_radius_ = explore_costmap_ros->getRobotRadius();
+    // FrontierCostsManager.cpp:10-16
+    alpha_ = parameterInstance.getValue<double>("frontierCostsManager/alpha");
+    beta_ = parameterInstance.getValue<double>("frontierCostsManager/beta");
+    planner_allow_unknown_ = parameterInstance.getValue<bool>("frontierCostsManager/planner_allow_unknown");
+    max_vx_ = parameterInstance.getValue<double>("frontierCostsManager/vx_max");
+    max_wx_ = parameterInstance.getValue<double>("frontierCostsManager/wz_max");
+
+    // the reference's calculator is kept for its planners only (roadmap A* / NavFn / Euclidean: out of the GPU path)
+    planner_ = std::make_shared<frontier_exploration::FrontierCostCalculator>(explore_costmap_ros);
+
+    if (fs_ctx_create(device_id, nullptr, &ctx_) != FS_OK)
+        throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) device or HIP runtime; there is no CPU fallback");
+    pushRayParams();
+    LOG_INFO("CostAssignerGPU: scoring on HIP device " << device_id);
+}
+
+CostAssignerGPU::~CostAssignerGPU()
+{
+    fs_ctx_destroy(ctx_);
+}
+
+void CostAssignerGPU::check(int rc, const char *what) const
+{
+    if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_last_error(ctx_));
+}
+
+void CostAssignerGPU::pushRayParams()
+{
+    fs_ray_params p;
+    std::memset(&p, 0, sizeof p);
+    p.max_camera_depth = max_camera_depth_;
+    p.delta_theta = delta_theta_;
+    p.camera_fov = camera_fov_;
+    p.robot_radius = robot_radius_;
+    p.n_rays = 0;                       // the reference loop `theta <= 2 * M_PI` (CostCalculator.cpp:36)
+    p.n_elev = 1;
+    p.elev[0] = 0.0;                    // 2-D costmap: one ring
+    p.obst_min = 240; p.obst_max = 254; p.trace_min = 255; p.trace_max = 255;   // CostCalculator.cpp:40
+    p.factor_max = 1.2; p.factor_min = 0.70;                                     // CostCalculator.cpp:186-188
+    if (polygon_xy_min_max_.size() >= 4) {
+        for (int i = 0; i < 4; ++i) p.polygon[i] = polygon_xy_min_max_[i];
+    } else {
+        p.polygon[0] = p.polygon[1] = -std::numeric_limits<double>::max();
+        p.polygon[2] = p.polygon[3] = std::numeric_limits<double>::max();
+    }
+    check(fs_set_ray_params(ctx_, &p), "fs_set_ray_params");
+    if (arrival_info_limits_set_) check(fs_set_arrival_limits(ctx_, max_arrival_info_gt_, min_arrival_info_gt_), "fs_set_arrival_limits");
+}
+
+void CostAssignerGPU::snapshotCostmap()
+{
+    // The reference reads the live costmap while the costmap thread may be writing it; here the upload
+    // is the snapshot point and is taken under the costmap's own mutex.
+    std::unique_lock<nav2_costmap_2d::Costmap2D::mutex_t> lock(*(costmap_->getMutex()));
+    const double origin[3] = {costmap_->getOriginX(), costmap_->getOriginY(), 0.0};
+    check(fs_upload_grid(ctx_, costmap_->getCharMap(), static_cast<int32_t>(costmap_->getSizeInCellsX()),
+                         static_cast<int32_t>(costmap_->getSizeInCellsY()), 1, origin, costmap_->getResolution()),
+          "fs_upload_grid");
+    if (arrival_info_limits_set_) check(fs_set_arrival_limits(ctx_, max_arrival_info_gt_, min_arrival_info_gt_), "fs_set_arrival_limits");
+}
+
+void CostAssignerGPU::setFrontierBlacklist(std::vector<FrontierPtr> &blacklist)
+{
+    std::lock_guard<std::mutex> lock(blacklist_mutex_);                          // FrontierCostsManager.cpp:217
+    for (auto frontier : blacklist) frontier_blacklist_[frontier] = true;
+}
+
+bool CostAssignerGPU::updateBoundaryPolygon(geometry_msgs::msg::PolygonStamped &explore_boundary)
+{
+    // CostAssigner.cpp:121-167, statement for statement (the Point32 narrowing included)
+    for (const auto &point32 : explore_boundary.polygon.points) {
+        geometry_msgs::msg::Point32 p = point32;
+        polygon_.points.push_back(p);
+    }
+    if (polygon_.points.empty()) {
+        geometry_msgs::msg::Point32 temp;
+        temp.x = layered_costmap_->getCostmap()->getOriginX();
+        temp.y = layered_costmap_->getCostmap()->getOriginY();
+        polygon_.points.push_back(temp);
+        temp.y = layered_costmap_->getCostmap()->getSizeInMetersY();
+        polygon_.points.push_back(temp);
+        temp.x = layered_costmap_->getCostmap()->getSizeInMetersX();
+        polygon_.points.push_back(temp);
+        temp.y = layered_costmap_->getCostmap()->getOriginY();
+        polygon_.points.push_back(temp);
+    }
+    double min_x_polygon = std::numeric_limits<double>::infinity();
+    double min_y_polygon = std::numeric_limits<double>::infinity();
+    double max_x_polygon = -std::numeric_limits<double>::infinity();
+    double max_y_polygon = -std::numeric_limits<double>::infinity();
+    for (const auto &point : polygon_.points) {
+        min_x_polygon = std::min(min_x_polygon, (double)point.x);
+        min_y_polygon = std::min(min_y_polygon, (double)point.y);
+        max_x_polygon = std::max(max_x_polygon, (double)point.x);
+        max_y_polygon = std::max(max_y_polygon, (double)point.y);
+    }
+    polygon_xy_min_max_.push_back(min_x_polygon);
+    polygon_xy_min_max_.push_back(min_y_polygon);
+    polygon_xy_min_max_.push_back(max_x_polygon);
+    polygon_xy_min_max_.push_back(max_y_polygon);
+    pushRayParams();                                                             // the clamp box of CostCalculator.cpp:47-48
+    return true;
+}
+
+bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geometry_msgs::msg::Pose start_pose_w)
+{
+    const double dmax = std::numeric_limits<double>::max();
+    planner_->reset();                                                           // FrontierCostsManager.cpp:51
+    snapshotCostmap();
+    if (!arrival_info_limits_set_) {                                             // :52, CostCalculator.cpp:123-191 (cached)
+        double max_value = 0, max_gt = 0, min_gt = 0;
+        check(fs_max_arrival(ctx_, &max_value, &max_gt, &min_gt), "fs_max_arrival");
+        if (max_value != 0.0) {
+            arrival_info_limits_set_ = true;
+            max_arrival_info_gt_ = max_gt;
+            min_arrival_info_gt_ = min_gt;
+        }
+    }
+    if (frontier_list.size() == 0) {                                             // :55-59
+        LOG_ERROR("No frontiers found from frontier search.");
+        return false;
+    }
+    if (polygon_xy_min_max_.size() <= 0) {                                       // :61-65
+        LOG_ERROR("FrontierPtr cannot be selected, no polygon.");
+        return false;
+    }
+    for (size_t i = 0; i < frontier_list.size(); ++i)                            // :25-45,69-72
+        for (size_t j = i + 1; j < frontier_list.size(); ++j)
+            if (frontier_list[i] == frontier_list[j]) throw std::runtime_error("Duplicate frontiers found.");
+
+    // ---- arrival information for the whole list: ONE launch instead of the loop of :74-119
+    const int32_t n = static_cast<int32_t>(frontier_list.size());
+    std::vector<double> goal(3 * static_cast<size_t>(n)), yaw(n);
+    std::vector<int32_t> fsize(n), arrival(n), argmax(n), status(n);
+    std::vector<uint8_t> black(n, 0), ach_in(n), ach(n);
+    {
+        std::lock_guard<std::mutex> lock(blacklist_mutex_);
+        for (int32_t i = 0; i < n; ++i) {
+            const auto &f = frontier_list[i];
+            const geometry_msgs::msg::Point &g = f->getGoalPoint();
+            goal[3 * i] = g.x; goal[3 * i + 1] = g.y; goal[3 * i + 2] = 0.0;
+            fsize[i] = f->getSize();
+            ach_in[i] = f->isAchievable() ? 1 : 0;
+            black[i] = frontier_blacklist_.count(f) > 0 ? 1 : 0;                 // :77
+        }
+    }
+    check(fs_score_arrival(ctx_, n, goal.data(), fsize.data(), black.data(), ach_in.data(), nullptr, arrival.data(),
+                           argmax.data(), yaw.data(), ach.data(), status.data()), "fs_score_arrival");
+
+    auto map_data = std::make_shared<slam_msgs::srv::GetMap::Response>();        // CostAssigner.cpp:37 (left empty there too)
+    for (int32_t i = 0; i < n; ++i) {
+        auto &frontier = frontier_list[i];
+        if (black[i]) {                                                          // :77-86
+            frontier->setArrivalInformation(0.0);
+            frontier->setGoalOrientation(0.0);
+            frontier->setFisherInformation(0.0);
+            frontier->setPathLength(dmax);
+            frontier->setPathLengthInM(dmax);
+            frontier->setWeightedCost(dmax);
+            continue;
+        }
+        frontier->setArrivalInformation(static_cast<double>(arrival[i]));        // CostCalculator.cpp:52 / :112
+        frontier->setGoalOrientation(yaw[i]);                                    // :53 / :119
+        frontier->setAchievability(ach[i] != 0);                                 // :78-82, :114-118
+        // planning stays with the reference (:98-109); it skips frontiers that are not achievable
+        if (planner_method_ == "A*PlannerDistance")
+            planner_->setPlanForFrontier(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
+        else if (planner_method_ == "RoadmapPlannerDistance")
+            planner_->setPlanForFrontierRoadmap(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
+        else
+            planner_->setPlanForFrontierEuclidean(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
+        planner_->recomputeNormalizationFactors(frontier);                       // :118
+    }
+
+    // ---- U1 utility + weighted cost (:126-205): ONE launch
+    std::vector<fs_record> rec(n);
+    std::vector<double> plen(n), phead(n), cost(n), au(n), du(n);
+    for (int32_t i = 0; i < n; ++i) {
+        auto &f = frontier_list[i];
+        std::memset(&rec[i], 0, sizeof(fs_record));
+        rec[i].arrival = black[i] ? 0 : arrival[i];
+        rec[i].flags = (!black[i] && f->isAchievable()) ? FS_FLAG_ACHIEVABLE : 0u;
+        plen[i] = f->getPathLength();
+        phead[i] = (black[i] || !f->isAchievable()) ? 0.0 : f->getPathHeading();
+    }
+    const int rc = fs_rank_candidates(ctx_, n, rec.data(), black.data(), plen.data(), phead.data(), alpha_, beta_, max_vx_, max_wx_,
+                                      cost.data(), au.data(), du.data(), nullptr);
+    if (rc == FS_E_RANGE) throw std::runtime_error("Cost out of bounds");        // :148-149,173-174
+    check(rc, "fs_rank_candidates");
+    for (int32_t i = 0; i < n; ++i) {
+        if (black[i]) continue;                                                  // its weighted cost is already max (:84)
+        frontier_list[i]->setWeightedCost(cost[i]);                              // :130 / :198
+        frontier_list[i]->setCost("arrival_gain_utility", au[i]);                // :131 / :199
+        frontier_list[i]->setCost("distance_utility", du[i]);                    // :132 / :200
+    }
+    return true;
+}
+
+bool CostAssignerGPU::getFrontierCosts(std::shared_ptr<GetFrontierCostsRequest> requestData,
+                                       std::shared_ptr<GetFrontierCostsResponse> resultData)
+{
+    setFrontierBlacklist(requestData->prohibited_frontiers);                     // CostAssigner.cpp:75
+    const bool costsResult = assignCosts(requestData->frontier_list, requestData->start_pose.pose);   // :79 (processOurApproach)
+    if (costsResult == false) {                                                  // :81-85
+        resultData->success = false;
+        return resultData->success;
+    }
+    resultData->success = true;
+    std::vector<FrontierPtr> frontiers_list;
+    std::vector<double> frontier_costs, frontier_distances, frontier_arrival_information;
+    for (auto &frontier : requestData->frontier_list) {                          // :92-99
+        frontiers_list.push_back(frontier);
+        frontier_costs.push_back(frontier->getWeightedCost());
+        frontier_distances.push_back(frontier->getPathLengthInM());
+        frontier_arrival_information.push_back(frontier->getArrivalInformation());
+    }
+    resultData->frontier_list = frontiers_list;
+    resultData->frontier_costs = frontier_costs;
+    resultData->frontier_distances = frontier_distances;
+    resultData->frontier_arrival_information = frontier_arrival_information;
+    if (resultData->frontier_list != requestData->frontier_list)                 // :105-108
+        throw std::runtime_error("Lists are not SAME!");
+    return resultData->success;
+}
+
+}  // namespace fitslam_frontier_ros2

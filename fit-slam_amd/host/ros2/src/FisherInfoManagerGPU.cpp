@@ -1,0 +1,160 @@
+// FisherInfoManagerGPU.cpp — see the header.
+#include "fitslam_frontier_ros2/FisherInfoManagerGPU.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <unordered_set>
+
+#include <nav2_util/geometry_utils.hpp>
+
+#include "roadmap_explorer/Parameters.hpp"
+#include "roadmap_explorer/util/Logger.hpp"
+
+namespace fitslam_frontier_ros2
+{
+
+FisherInformationManagerGPU::FisherInformationManagerGPU(std::shared_ptr<nav2_util::LifecycleNode> node, int device_id,
+                                                         const std::string &lookup_file)
+    : lookup_file_(lookup_file), node_(node)
+{
+    if (fs_ctx_create(device_id, nullptr, &ctx_) != FS_OK)
+        throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) device or HIP runtime; there is no CPU fallback");
+    // FisherInfoManager.cpp:63-64: radius 14.0, observation-angle filter disabled in the request (4.0 > pi).  Which
+    // landmarks the un-vendored server returned beyond that is unknown; the scorer's definition is the
+    // 14 m range sphere intersected with a 1.0 rad cone about the camera's +x axis (LoadLookupMain.cpp:115).
+    fs_fim_params vis;
+    vis.max_dist = 14.0;
+    vis.max_angle = 1.0;
+    check(fs_set_fim_params(ctx_, &vis), "fs_set_fim_params");
+    loadLookupTable();                                                           // :10
+
+    client_node_ = rclcpp::Node::make_shared("FIMManagerGPUClient");             // :9 (same pattern: a node of its own)
+    map_data_subscription_ = client_node_->create_subscription<slam_msgs::msg::MapData>(
+        "map_data", 10, std::bind(&FisherInformationManagerGPU::mapDataCallback, this, std::placeholders::_1));
+    executor_ = std::make_shared<rclcpp::executors::SingleThreadedExecutor>();
+    executor_->add_node(client_node_);
+    spin_thread_ = std::thread([this]() { executor_->spin(); });
+}
+
+FisherInformationManagerGPU::~FisherInformationManagerGPU()
+{
+    // (the reference's destructor calls rclcpp::shutdown(), FisherInfoManager.cpp:22-28 — a latent bug that takes the
+    // whole process down with the plugin; not reproduced)
+    if (executor_) executor_->cancel();
+    if (spin_thread_.joinable()) spin_thread_.join();
+    map_data_subscription_.reset();
+    client_node_.reset();
+    fs_ctx_destroy(ctx_);
+}
+
+void FisherInformationManagerGPU::check(int rc, const char *what) const
+{
+    if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_last_error(ctx_));
+}
+
+void FisherInformationManagerGPU::generateLookupTable(float minX, float maxX, float minY, float maxY, float minZ, float maxZ)
+{
+    std::lock_guard<std::mutex> lock(ctx_mutex_);
+    const float bounds[6] = {minX, maxX, minY, maxY, minZ, maxZ};
+    check(fs_lookup_generate(ctx_, bounds), "fs_lookup_generate");               // FisherInfoManager.cpp:117-229
+    check(fs_lookup_save(ctx_, lookup_file_.c_str()), "fs_lookup_save");         // byte-compatible 16-B records
+}
+
+void FisherInformationManagerGPU::loadLookupTable()
+{
+    std::lock_guard<std::mutex> lock(ctx_mutex_);
+    if (fs_lookup_load(ctx_, lookup_file_.c_str()) != FS_OK)                     // :231-262
+        throw std::runtime_error("Cannot load lookup table. Does it exist in the path?");
+}
+
+void FisherInformationManagerGPU::setVisibility(double max_dist, double max_angle)
+{
+    std::lock_guard<std::mutex> lock(ctx_mutex_);
+    fs_fim_params vis;
+    vis.max_dist = max_dist;
+    vis.max_angle = max_angle;
+    check(fs_set_fim_params(ctx_, &vis), "fs_set_fim_params");
+}
+
+void FisherInformationManagerGPU::setLandmarks(const std::vector<float> &xyz_world)
+{
+    std::lock_guard<std::mutex> lock(ctx_mutex_);
+    check(fs_upload_landmarks(ctx_, xyz_world.data(), static_cast<int32_t>(xyz_world.size() / 3)), "fs_upload_landmarks");
+    have_landmarks_ = true;
+}
+
+void FisherInformationManagerGPU::mapDataCallback(const slam_msgs::msg::MapData::SharedPtr map_data)
+{
+    // The map points of every key-frame (nodes[].word_pts, world frame).  A map point observed from several key-frames
+    // appears once per key-frame in the message; the crowding discount counts landmarks per voxel, so duplicates are
+    // removed here (exact coordinates: they are copies of one map point).
+    struct Key { float x, y, z; bool operator==(const Key &o) const { return x == o.x && y == o.y && z == o.z; } };
+    struct KeyHash {
+        size_t operator()(const Key &k) const
+        {
+            uint32_t b[3];
+            std::memcpy(b, &k, sizeof b);
+            size_t h = 0;
+            for (uint32_t v : b) h ^= std::hash<uint32_t>{}(v) + 0x9e3779b9u + (h << 6) + (h >> 2);
+            return h;
+        }
+    };
+    std::unordered_set<Key, KeyHash> seen;
+    std::vector<float> xyz;
+    for (const auto &node : map_data->nodes) {
+        for (const auto &p : node.word_pts) {
+            const Key k{static_cast<float>(p.x), static_cast<float>(p.y), static_cast<float>(p.z)};
+            if (!std::isfinite(k.x) || !std::isfinite(k.y) || !std::isfinite(k.z)) continue;
+            if (!seen.insert(k).second) continue;
+            xyz.push_back(k.x); xyz.push_back(k.y); xyz.push_back(k.z);
+        }
+    }
+    setLandmarks(xyz);
+    LOG_INFO("FisherInformationManagerGPU: staged " << xyz.size() / 3 << " landmarks from map_data");
+}
+
+bool FisherInformationManagerGPU::poseInformation(const std::vector<geometry_msgs::msg::Pose> &poses, std::vector<float> &information)
+{
+    information.assign(poses.size(), 0.0f);
+    if (poses.empty()) return true;
+    if (!have_landmarks_) {                                                      // the reference's "service not found" (:52-57)
+        LOG_ERROR("No map_data received yet for fisher information");
+        return false;
+    }
+    std::vector<double> pose7(poses.size() * 7);
+    for (size_t i = 0; i < poses.size(); ++i) {
+        const auto &p = poses[i];
+        double *o = &pose7[7 * i];
+        o[0] = p.position.x; o[1] = p.position.y; o[2] = p.position.z;
+        o[3] = p.orientation.x; o[4] = p.orientation.y; o[5] = p.orientation.z; o[6] = p.orientation.w;
+    }
+    std::lock_guard<std::mutex> lock(ctx_mutex_);
+    return fs_score_fim(ctx_, static_cast<int32_t>(poses.size()), pose7.data(), information.data(),
+                        nullptr, nullptr, nullptr, nullptr, nullptr) == FS_OK;
+}
+
+bool FisherInformationManagerGPU::isPoseSafe(geometry_msgs::msg::Pose &given_pose, bool /*exhaustiveSearch*/, float &information)
+{
+    const double fisher_information_threshold =
+        parameterInstance.getValue<double>("fisherInformation.fisher_information_threshold");    // FisherInfoManager.cpp:41
+    std::vector<float> info;
+    if (!poseInformation({given_pose}, info)) return false;                      // :52-57,73-77: failure -> false
+    LOG_WARN("Total information: " << info[0]);                                  // :99
+    information = info[0];                                                       // :100
+    return info[0] > fisher_information_threshold;                               // :112-114
+}
+
+bool FisherInformationManagerGPU::isPoseSafe(geometry_msgs::msg::Point point_from, geometry_msgs::msg::Point point_to, bool exhaustiveSearch)
+{
+    // FisherInfoManager.cpp:31-37 with getRelativePoseGivenTwoPoints (roadmap_explorer/util/GeometryUtils.hpp): position
+    // = point_from, orientation = yaw of the segment about Z
+    geometry_msgs::msg::Pose relative_pose;
+    relative_pose.position = point_from;
+    const double yaw = std::atan2(point_to.y - point_from.y, point_to.x - point_from.x);
+    relative_pose.orientation = nav2_util::geometry_utils::orientationAroundZAxis(yaw);
+    float information;
+    return isPoseSafe(relative_pose, exhaustiveSearch, information);
+}
+
+}  // namespace fitslam_frontier_ros2

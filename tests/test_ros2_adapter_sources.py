@@ -1,0 +1,81 @@
+"""The ROS 2 adapter ships as reviewable source (SURVEY.md §7 step 9, §8(b) "Plugin interface").
+ROS 2 / nav2 / BehaviorTree.CPP / pluginlib are absent from the build image, so it cannot be compiled here; these checks
+keep it complete and in step with the C ABI it calls."""
+import os
+import re
+import xml.etree.ElementTree as ET
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "fit-slam_amd", "host", "ros2")
+
+
+def _read(*parts):
+    return open(os.path.join(PKG, *parts)).read()
+
+
+def _declared_abi():
+    text = open(os.path.join(ROOT, "include", "fitslam_frontier.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text))
+
+
+def test_adapter_files_exist_and_have_no_elisions():
+    files = ["CMakeLists.txt", "package.xml", "fisher_information_bt_plugin_gpu.xml", "README.md",
+             "include/fitslam_frontier_ros2/CostAssignerGPU.hpp", "include/fitslam_frontier_ros2/FisherInfoManagerGPU.hpp",
+             "include/fitslam_frontier_ros2/FisherInfoBTPluginGPU.hpp",
+             "src/CostAssignerGPU.cpp", "src/FisherInfoManagerGPU.cpp", "src/FisherInfoBTPluginGPU.cpp"]
+    for f in files:
+        path = os.path.join(PKG, f)
+        assert os.path.exists(path), f
+        if f.endswith((".cpp", ".hpp")):
+            src = open(path).read()
+            assert "/* ..." not in src and "/* …" not in src and "TODO" not in src, f      # complete source, not a sketch
+            assert src.count("{") == src.count("}") and src.count("(") == src.count(")"), f
+
+
+def test_plugin_registers_the_reference_node_ids_and_exports_the_class():
+    src = _read("src", "FisherInfoBTPluginGPU.cpp")
+    assert "void FisherInfoBTPluginGPU::registerNodes(BT::BehaviorTreeFactory &factory" in src
+    assert '"EvaluateFisherInformation"' in src and "MarkLethalFOV" in src
+    assert re.search(r"PLUGINLIB_EXPORT_CLASS\(\s*roadmap_explorer::FisherInfoBTPluginGPU,\s*roadmap_explorer::BTPlugin\)", src)
+    assert 'BT::InputPort<bool>("exhaustive_landmark_search")' in src and '"latest_robot_pose"' in src
+    assert 'lookupTransform("map", "base_footprint"' in src
+    hdr = _read("include", "fitslam_frontier_ros2", "FisherInfoBTPluginGPU.hpp")
+    assert "class FisherInfoBTPluginGPU : public BTPlugin" in hdr and "override;" in hdr
+    x = ET.parse(os.path.join(PKG, "fisher_information_bt_plugin_gpu.xml")).getroot()
+    assert x.tag == "library" and x.attrib["path"] == "fitslam_frontier_bt_plugins"
+    cls = x.find("class")
+    assert cls.attrib["type"] == "roadmap_explorer::FisherInfoBTPluginGPU" and cls.attrib["base_class_type"] == "roadmap_explorer::BTPlugin"
+
+
+def test_cmake_is_guarded_and_exports_the_plugin_description():
+    cm = _read("CMakeLists.txt")
+    assert "find_package(roadmap_explorer QUIET)" in cm and "find_package(frontier_exploration QUIET)" in cm
+    assert re.search(r"if\(NOT ament_cmake_FOUND OR NOT roadmap_explorer_FOUND\).*?return\(\)", cm, flags=re.S)
+    assert "pluginlib_export_plugin_description_file(roadmap_explorer fisher_information_bt_plugin_gpu.xml)" in cm
+    assert "add_library(fitslam_frontier_bt_plugins SHARED" in cm and "libfitslam_frontier.so" in cm
+    for f in ("src/FisherInfoBTPluginGPU.cpp", "src/FisherInfoManagerGPU.cpp", "src/CostAssignerGPU.cpp"):
+        assert f in cm
+    ET.parse(os.path.join(PKG, "package.xml"))
+
+
+def test_adapter_calls_only_declared_abi_entry_points():
+    declared = _declared_abi()
+    used = set()
+    for f in ("src/CostAssignerGPU.cpp", "src/FisherInfoManagerGPU.cpp", "src/FisherInfoBTPluginGPU.cpp"):
+        used |= set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", _read(*f.split("/"))))
+    assert used and used <= declared, used - declared
+    # the batched calls that replace the reference's per-frontier loop and per-pose service call
+    assert {"fs_score_arrival", "fs_rank_candidates", "fs_max_arrival", "fs_upload_grid", "fs_score_fim",
+            "fs_upload_landmarks", "fs_lookup_load"} <= used
+
+
+def test_cost_assigner_keeps_the_reference_interface():
+    hdr = _read("include", "fitslam_frontier_ros2", "CostAssignerGPU.hpp")
+    for sig in ("explicit CostAssignerGPU(std::shared_ptr<nav2_costmap_2d::Costmap2DROS> explore_costmap_ros",
+                "bool updateBoundaryPolygon(geometry_msgs::msg::PolygonStamped &explore_boundary);",
+                "bool getFrontierCosts(std::shared_ptr<frontier_exploration::GetFrontierCostsRequest> requestData,"):
+        assert sig in hdr, sig
+    src = _read("src", "CostAssignerGPU.cpp")
+    for msg in ('"Duplicate frontiers found."', '"Cost out of bounds"', '"Lists are not SAME!"'):
+        assert msg in src, msg                                   # the reference's exceptions, same texts
