@@ -130,7 +130,7 @@ struct fs_ctx {
     DevBuf<int32_t> d_seg_traced, d_seg_unknown, d_seg_all, d_brick_xyz, d_bad;
     DevBuf<unsigned long long> d_count;
     bool opt_sort = true;
-    int opt_layout = 0;            // 0 auto, 1 row-major walk, 2 bricked walk
+    int opt_layout = 0;            // 0 auto, 1 row-major walk, 2 bricked walk, 3 LDS-staged fan (planar fans; else auto)
 
     // timing
     bool timing = false;
@@ -396,6 +396,18 @@ int fill_ray_args(fs_ctx *c, FsRayArgs &a)
     a.n_yaw = c->n_yaw; a.n_elev = c->n_elev; a.window = c->window;
     a.max_length = (unsigned int)(p.max_camera_depth / c->res);             // CostCalculator.cpp:28
     a.bricked = use_bricks(c, (double)a.max_length);
+    // Planar fans (one elevation ring at 0: the reference's own case) of up to 64 cells CAN walk an LDS copy of the
+    // start cell's neighbourhood (fs_raymarch.hip, WalkTile).  Measured on the reference defaults (REF2D: 512^2 map,
+    // 20 k fans of 63 rays, L = 40; profiles/r02/ref2d_ray_layouts.json): row-major 0.065 ms, bricked
+    // 0.084 ms, LDS-staged 0.081 ms — a 2-D map sits in L1/L2 and the kernel is bound by its per-fan set-up, so the
+    // automatic choice stays the row-major walk and the LDS walk is only taken on request ("ray.layout" = 3).
+    const bool planar = c->n_elev == 1 && p.elev[0] == 0.0;
+    if (planar && a.max_length >= 1 && a.max_length <= 64 && c->opt_layout == 3) {
+        a.bricked = 2;
+        a.tile_stride = (int32_t)((2 * a.max_length + 1 + 3 + 3) & ~3u);        // the row, + up to 3 cells of alignment slack, rounded up to 4
+        const uint32_t dw = (uint32_t)a.tile_stride / 4;
+        a.tile_magic = (uint32_t)((((uint64_t)1 << 32) + dw - 1) / dw);         // exact floor(i / dw) for i < 2^16 (i < 129 * 34)
+    }
     a.obst_min = p.obst_min; a.obst_max = p.obst_max; a.trace_min = p.trace_min; a.trace_max = p.trace_max;
     a.clamp = 1;
     // CostCalculator.cpp:47-48, getSizeInMeters = (size - 1 + 0.5) * resolution
@@ -994,7 +1006,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 2) { c->opt_layout = (int)value; return FS_OK; }
+    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 3) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);

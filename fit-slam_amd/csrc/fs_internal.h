@@ -40,7 +40,9 @@ struct FsRayArgs {
     uint32_t max_length;       // (unsigned)(max_camera_depth / resolution), CostCalculator.cpp:28
     int32_t obst_min, obst_max, trace_min, trace_max;
     int32_t clamp;             // CostCalculator.cpp:47-48 (1) or setMaxArrivalInformation (0)
-    int32_t bricked;           // walk the 8x8x2-brick copy (long rays) instead of the row-major image
+    int32_t bricked;           // 0: row-major image, 1: the 8x8x2-brick copy (long rays), 2: the fan's neighbourhood staged in LDS (planar fans)
+    int32_t tile_stride;       // LDS tile of layout 2: (2 * max_length + 1) rows of tile_stride bytes (a multiple of 4)
+    uint32_t tile_magic;       // ceil(2^32 / (tile_stride / 4)): row of a staged dword without an integer division
     double lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // folded clamp bounds: max(poly_min, origin), min(poly_max, origin + sizeInMeters)
     double footprint_radius;   // ceil(robot_radius / resolution)
     double delta_theta, half_fov;

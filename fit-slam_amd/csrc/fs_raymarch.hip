@@ -15,8 +15,11 @@
 // wave-shuffle reduction.  This is HBM/L2-bound byte gather: no MFMA.
 #include "fs_internal.h"
 
+#include <type_traits>
+
 #define FS_RAY_WAVES 4          // candidates per workgroup
 #define FS_RAY_UNROLL 4         // speculative cell loads in flight per lane
+#define FS_TILE_BATCH 7         // dwords per lane in flight while a fan's neighbourhood is staged into LDS
 
 namespace {
 
@@ -40,7 +43,7 @@ __device__ __forceinline__ bool world_to_map(const FsGridDev &g, double wx, doub
 
 __device__ __forceinline__ int sign_ref(int x) { return x > 0 ? 1 : -1; }   // Helpers.hpp:113-116
 
-// Two interchangeable walks over the same cell sequence (selected per launch, FsRayArgs::bricked):
+// Three interchangeable walks over the same cell sequence (selected per launch, FsRayArgs::bricked):
 //
 // WalkLinear — the reference's own formulation on the dense row-major image: a linear offset, constant strides per
 // axis, bresenham2D's body (DEP/src/Helpers.cpp:21-27) with a second minor axis.  Cheapest in ALU; rows only give
@@ -66,6 +69,29 @@ struct WalkBricked {
     int ex, ey, ez;
     uint32_t end;
 };
+
+// WalkTile — for PLANAR fans (one elevation ring at 0: the reference's 2-D case, DEP/src/CostCalculator.cpp:36-58): a
+// walk of at most L = max_length steps never leaves the (2L+1) x (2L+1) cells around the start cell, so the wave stages
+// that neighbourhood in LDS once per candidate (81 x 84 B = 6.8 KB at the reference's 2 m / 0.05 m) with coalesced
+// dword loads and every ray of the fan walks the LDS copy with bresenham2D's own two-axis body: one ds_read_u8 per step
+// instead of a 64-lane byte gather that touches ~40 cache lines.
+struct WalkTile {
+    const uint8_t *tile;     // LDS
+    uint32_t offset;
+    uint32_t abs_da, abs_db;
+    int err_b;
+    int off_a, off_b;
+    uint32_t end;
+};
+
+__device__ __forceinline__ void walk_step(WalkTile &w)
+{
+    w.offset += (uint32_t)w.off_a;
+    w.err_b += (int)w.abs_db;
+    if ((uint32_t)w.err_b >= w.abs_da) { w.offset += (uint32_t)w.off_b; w.err_b -= (int)w.abs_da; }
+}
+
+__device__ __forceinline__ int walk_cell(const FsGridDev &, const WalkTile &w) { return (int)w.tile[w.offset]; }
 
 __device__ __forceinline__ void walk_step(WalkLinear &w)
 {
@@ -146,15 +172,89 @@ __device__ __forceinline__ void walk_init(WalkBricked &w, const FsGridDev &, uin
     w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
 }
 
+struct TileGeom {
+    uint8_t *tile;           // this wave's LDS tile
+    int x0, y0;              // grid cell of tile byte 0 (x0 a multiple of 4, possibly negative)
+    int stride;
+};
+
+__device__ __forceinline__ void walk_init(WalkTile &w, const TileGeom &t, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, double max_length)
+{
+    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0);
+    w.tile = t.tile;
+    w.offset = (uint32_t)(((int)y0 - t.y0) * t.stride + ((int)x0 - t.x0));
+    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy);
+    const int odx = sign_ref(dx), ody = sign_ref(dy) * t.stride;
+    if (adx >= ady) { w.abs_da = adx; w.abs_db = ady; w.off_a = odx; w.off_b = ody; }      // Helpers.cpp:56-75
+    else { w.abs_da = ady; w.abs_db = adx; w.off_a = ody; w.off_b = odx; }                 // Helpers.cpp:77-93
+    w.err_b = (int)(w.abs_da / 2);
+    w.end = walk_visits(dx, dy, 0, w.abs_da, max_length);
+}
+
+// Stage the neighbourhood of the start cell (slice z0) into the wave's tile.  Cells beyond the grid are filled with
+// 255; they are never visited (a walk stays inside the bounding box of its two on-map end cells).
+__device__ __forceinline__ void stage_tile(const FsRayArgs &a, const TileGeom &t, uint32_t z0, int lane)
+{
+    const int nx = a.grid.nx, ny = a.grid.ny;
+    const int rows = 2 * (int)a.max_length + 1;
+    const uint8_t *slice = a.grid.cells + (size_t)z0 * (size_t)ny * (size_t)nx;
+    const int dw_per_row = t.stride >> 2;
+    uint32_t *tile32 = reinterpret_cast<uint32_t *>(t.tile);
+    const bool aligned = (nx & 3) == 0 && ((((size_t)ny * (size_t)nx) & 3) == 0);
+    // batches of FS_TILE_BATCH dwords per lane: all loads of a batch are issued before the first LDS store, so their
+    // latencies overlap (one load per iteration ran at one L2 round trip per 256 B)
+    const int total = rows * dw_per_row;
+    for (int base = 0; base < total; base += 64 * FS_TILE_BATCH) {
+        uint32_t v[FS_TILE_BATCH];
+#pragma unroll
+        for (int u = 0; u < FS_TILE_BATCH; ++u) {
+            const int i = base + u * 64 + lane;
+            const int r = (int)__umulhi((uint32_t)i, a.tile_magic);      // i / dw_per_row (exact: i < 2^16, see the launcher)
+            const int d = i - r * dw_per_row;
+            const int y = t.y0 + r, x = t.x0 + 4 * d;
+            v[u] = 0xffffffffu;
+            if (i < total && y >= 0 && y < ny) {
+                const uint8_t *row = slice + (size_t)y * (size_t)nx;
+                if (aligned && x >= 0 && x + 3 < nx) {
+                    v[u] = *reinterpret_cast<const uint32_t *>(row + x);
+                } else {
+                    uint32_t q = 0u;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int xb = x + b;
+                        const uint32_t c = (xb >= 0 && xb < nx) ? (uint32_t)row[xb] : 255u;
+                        q |= c << (8 * b);
+                    }
+                    v[u] = q;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FS_TILE_BATCH; ++u) {
+            const int i = base + u * 64 + lane;
+            if (i < total) tile32[i] = v[u];
+        }
+    }
+}
+
 // The start cell is the same for every ray of a fan: its worldToMap (three fp64 divisions) is done once per candidate;
 // a start point off the map fails every ray, like the reference's `||` of the two conversions (Helpers.cpp:40).
 template <typename Walk>
-__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, bool start_ok, uint32_t x0, uint32_t y0, uint32_t z0,
+__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, const TileGeom &, bool start_ok, uint32_t x0, uint32_t y0, uint32_t z0,
                                           double wx, double wy, double wz, Walk &w)
 {
     uint32_t x1, y1, z1;
     if (!world_to_map(a.grid, wx, wy, wz, x1, y1, z1) || !start_ok) return false;
     walk_init(w, a.grid, x0, y0, z0, x1, y1, z1, (double)a.max_length);
+    return true;
+}
+// planar fan: the end cell lies in the start cell's slice (direction z component 0, the clamp keeps the cell)
+__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, const TileGeom &t, bool start_ok, uint32_t x0, uint32_t y0, uint32_t,
+                                          double wx, double wy, double wz, WalkTile &w)
+{
+    uint32_t x1, y1, z1;
+    if (!world_to_map(a.grid, wx, wy, wz, x1, y1, z1) || !start_ok) return false;
+    walk_init(w, t, x0, y0, x1, y1, (double)a.max_length);
     return true;
 }
 
@@ -230,6 +330,17 @@ void fs_raymarch_kernel(const FsRayArgs a)
     bool fail = false;
     uint32_t sxm = 0, sym = 0, szm = 0;
     const bool start_ok = active && world_to_map(a.grid, sx, sy, sz, sxm, sym, szm);
+    constexpr bool kTile = std::is_same<Walk, WalkTile>::value;
+    TileGeom tg{nullptr, 0, 0, 0};
+    if (kTile) {
+        const int L = (int)a.max_length;
+        tg.stride = a.tile_stride;
+        tg.tile = reinterpret_cast<uint8_t *>(fs_ray_lds + FS_RAY_WAVES * a.n_yaw) + (size_t)wave * (size_t)(2 * L + 1) * (size_t)a.tile_stride;
+        tg.x0 = ((int)sxm - L) & ~3;                        // floor to a multiple of 4 (also for negative values)
+        tg.y0 = (int)sym - L;
+        if (start_ok && !black) stage_tile(a, tg, szm, lane);
+        __syncthreads();                                    // the tile is written and read by the same wave; all waves pass here
+    }
     if (active && !black) {
         for (int r = lane; r < n_rays; r += 64) {
             const int i = r % a.n_yaw;
@@ -244,7 +355,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
             }
             Walk w;
             int count = 0;
-            if (ray_setup(a, start_ok, sxm, sym, szm, wx, wy, wz, w)) count = ray_march(a, w);
+            if (ray_setup(a, tg, start_ok, sxm, sym, szm, wx, wy, wz, w)) count = ray_march(a, w);
             else fail = true;
             if (count) atomicAdd(&ysum[i], count);
             if (a.ray_counts) a.ray_counts[(size_t)c * n_rays + r] = count;
@@ -269,15 +380,19 @@ void fs_raymarch_kernel(const FsRayArgs a)
     const int ri = (int)a.footprint_radius;
     const int side = 2 * ri + 1;
     bool lethal = false;
-    for (int t = lane; t < side * side; t += 64) {
-        const int dx = t / side - ri, dy = t % side - ri;
-        if ((double)(dx * dx + dy * dy) <= a.footprint_radius * a.footprint_radius) {
-            const uint32_t x = sxm + (uint32_t)dx, y = sym + (uint32_t)dy;
-            if (x < (uint32_t)a.grid.nx && y < (uint32_t)a.grid.ny) {
-                if (a.grid.bricks[fs_brick_offset((uint32_t)a.grid.bx, (uint32_t)a.grid.by, x, y, szm)] == 254) lethal = true;
+    auto scan_disc = [&](auto cell_at) {
+        for (int t = lane; t < side * side; t += 64) {
+            const int dx = t / side - ri, dy = t % side - ri;
+            if ((double)(dx * dx + dy * dy) <= a.footprint_radius * a.footprint_radius) {
+                const uint32_t x = sxm + (uint32_t)dx, y = sym + (uint32_t)dy;
+                if (x < (uint32_t)a.grid.nx && y < (uint32_t)a.grid.ny && cell_at(x, y) == 254) lethal = true;
             }
         }
-    }
+    };
+    if (kTile && ri <= (int)a.max_length)        // the disc lies inside the staged square: read the LDS copy
+        scan_disc([&](uint32_t x, uint32_t y) -> int { return tg.tile[((int)y - tg.y0) * tg.stride + ((int)x - tg.x0)]; });
+    else
+        scan_disc([&](uint32_t x, uint32_t y) -> int { return a.grid.bricks[fs_brick_offset((uint32_t)a.grid.bx, (uint32_t)a.grid.by, x, y, szm)]; });
     lethal = __any(lethal);
     const int fsize = a.frontier_size ? a.frontier_size[c] : 0;
     if (lethal && (double)fsize < 10.0) ach = 0;           // CostCalculator.cpp:77-82
@@ -366,7 +481,16 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
     int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
     if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
-    if (a.bricked) hipLaunchKernelGGL(fs_raymarch_kernel<WalkBricked>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    if (a.bricked == 2) {
+        const size_t tile = (size_t)(2 * a.max_length + 1) * (size_t)a.tile_stride;
+        const size_t lds_t = lds + FS_RAY_WAVES * tile;
+        auto kernel = fs_raymarch_kernel<WalkTile>;
+        if (lds_t > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds_t, s, a);
+    } else if (a.bricked) hipLaunchKernelGGL(fs_raymarch_kernel<WalkBricked>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else hipLaunchKernelGGL(fs_raymarch_kernel<WalkLinear>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();
 }

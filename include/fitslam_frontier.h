@@ -114,7 +114,9 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * bounding-sphere culling of the landmark cloud; 0 tests every landmark (brute force; identical results).
  * "ray.sort" (default 1): ray-march candidates in Morton order of their goal cell (lists of >= 2048).
  * "ray.layout" (default 0): which copy of the grid the ray walks read — 0 picks by ray length (row-major image below
- * 96 cells, 8x8x2-brick copy from there on), 1 / 2 force the row-major / bricked walk (identical results).
+ * 96 cells, 8x8x2-brick copy from there on: the measured winners), 1 / 2 force the row-major / bricked walk, 3 walks an
+ * LDS copy of the start cell's neighbourhood where the fan is planar and at most 64 cells deep, else as 0 (identical
+ * results in every case).
  * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
  * landmarks scanned, in 32nds, that decides the number of scoring passes: DESIGN.md 4.2). */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);

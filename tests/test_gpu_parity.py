@@ -431,7 +431,7 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
             _setup_scorer(scorer, w)
             mx_o = oracle.max_arrival_information(G, P)
             want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], n_threads=8)
-            for layout in (1, 2, 0):
+            for layout in (1, 2, 3, 0):                        # 3: LDS-staged fan where the fan is planar, else as 0
                 scorer.set_option("ray.layout", layout)
                 assert scorer.max_arrival() == mx_o
                 _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
@@ -454,6 +454,47 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
             if r["ok"]:
                 assert (res[2]["traced"][i], bool(res[2]["hit"][i]), res[2]["unknown"][i], res[2]["all"][i]) == \
                     (r["traced"], r["hit"], r["unknown"], r["all"]), i
+    finally:
+        scorer.set_option("ray.layout", 0)
+
+
+def test_lds_staged_fan_walk_equals_the_other_walks(fs, oracle, scorer):
+    """Planar fans walk an LDS copy of the start cell's neighbourhood (WalkTile): per-ray counts, arrival, argmax, yaw,
+    achievability and status identical to the oracle and to the row-major walk — grids whose row length is not a
+    multiple of 4 (byte staging), goals at the map border (tile partly off the grid), goals off the map, depths 1..64,
+    a z slice of a 3-D grid, visitor ranges that overlap."""
+    rng = np.random.default_rng(301)
+    try:
+        for nx, ny, nz, depth in ((101, 67, 1, 40), (96, 96, 1, 64), (50, 131, 1, 7), (64, 64, 3, 40), (33, 35, 1, 1)):
+            cells = rng.choice(np.array([0, 0, 0, 0, 255, 255, 255, 254, 253, 240], np.uint8), size=(nz, ny, nx))
+            origin = (-0.05 * nx / 2, -0.05 * ny / 2, 0.0)
+            n = 300
+            goals = np.zeros((n, 3))
+            goals[:, 0] = rng.uniform(origin[0] - 0.1, origin[0] + nx * 0.05 + 0.1, size=n)      # some off the map
+            goals[:, 1] = rng.uniform(origin[1] - 0.1, origin[1] + ny * 0.05 + 0.1, size=n)
+            goals[:40, 0] = origin[0] + rng.uniform(0.0, 0.2, size=40)                            # hugging the borders
+            goals[40:80, 1] = origin[1] + ny * 0.05 - rng.uniform(0.0, 0.2, size=40)
+            goals[:, 2] = rng.integers(0, nz, size=n) * 0.05 + 0.01
+            fsize = rng.integers(1, 31, size=n).astype(np.int32)
+            black = (rng.random(n) < 0.03).astype(np.uint8)
+            for obst, trace in (((240, 254), (255, 255)), ((250, 255), (0, 255))):
+                kw = dict(max_camera_depth=depth * 0.05, delta_theta=0.10, camera_fov=1.04, robot_radius=0.60, n_rays=0, elev=(0.0,),
+                          obst=obst, trace=trace, polygon=(origin[0] + 0.3, origin[1] + 0.1, origin[0] + nx * 0.05 - 0.2, origin[1] + ny * 0.05 - 0.3))
+                G = oracle.Grid(cells, origin=origin, resolution=0.05)
+                P = oracle.RayParams(**kw)
+                scorer.set_ray_params(**kw)
+                scorer.upload_grid(cells, origin, 0.05)
+                mx_o = oracle.max_arrival_information(G, P)
+                want = oracle.arrival_information(G, P, goals, fsize, black, min_gt=mx_o["min_gt"], faithful=True)
+                res = {}
+                for layout in (3, 1):
+                    scorer.set_option("ray.layout", layout)
+                    assert scorer.max_arrival() == mx_o
+                    res[layout] = scorer.score_arrival(goals, fsize, black, want_ray_counts=True)
+                    _assert_arrival_equal(res[layout], want)
+                    np.testing.assert_array_equal(res[layout]["yaw"], want["yaw"])
+                    np.testing.assert_array_equal(res[layout]["ray_counts"], want["ray_counts"])
+                assert (want["status"] == 1).sum() > 0 and (want["arrival"] > 0).sum() > 0
     finally:
         scorer.set_option("ray.layout", 0)
 
