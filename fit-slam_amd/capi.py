@@ -21,7 +21,7 @@ FS_MAX_ELEV = 16
 EXPORTED_SYMBOLS = [
     "fs_abi_version", "fs_ctx_create", "fs_ctx_destroy", "fs_last_error", "fs_synchronize",
     "fs_enable_kernel_timing", "fs_kernel_time", "fs_set_option", "fs_get_counter",
-    "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_upload_grid_bricks", "fs_frontier_cells", "fs_max_arrival", "fs_set_arrival_limits",
+    "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_upload_grid_bricks", "fs_frontier_cells", "fs_frontier_clusters", "fs_max_arrival", "fs_set_arrival_limits",
     "fs_score_arrival", "fs_trace_segments",
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim", "fs_information_frontier_pair",
@@ -37,6 +37,16 @@ assert RECORD_DTYPE.itemsize == 32
 class KeyframeParamsC(C.Structure):
     _fields_ = [("max_depth", C.c_double), ("hfov", C.c_double), ("max_depth_error", C.c_double),
                 ("q_diag", C.c_float), ("radius", C.c_double)]
+
+
+class FrontierClusterC(C.Structure):
+    _fields_ = [("label", C.c_int32), ("size", C.c_int32), ("centroid_x", C.c_double), ("centroid_y", C.c_double),
+                ("min_x", C.c_int32), ("min_y", C.c_int32), ("max_x", C.c_int32), ("max_y", C.c_int32)]
+
+
+CLUSTER_DTYPE = np.dtype([("label", "<i4"), ("size", "<i4"), ("centroid_x", "<f8"), ("centroid_y", "<f8"),
+                          ("min_x", "<i4"), ("min_y", "<i4"), ("max_x", "<i4"), ("max_y", "<i4")])
+assert CLUSTER_DTYPE.itemsize == C.sizeof(FrontierClusterC) == 40
 
 
 class RayParamsC(C.Structure):
@@ -88,6 +98,7 @@ def load_library(build: bool = True):
     L.fs_upload_grid.argtypes = [vp, vp, i32, i32, i32, C.POINTER(dbl * 3), dbl]
     L.fs_upload_grid_bricks.argtypes = [vp, i32, i32, i32, C.POINTER(dbl * 3), dbl, C.c_uint8, i64, vp, vp]
     L.fs_frontier_cells.argtypes = [vp, i32, vp, C.POINTER(i64)]
+    L.fs_frontier_clusters.argtypes = [vp, C.POINTER(dbl * 2), i32, dbl, i32, vp, i32, vp, C.POINTER(i32), C.POINTER(i64)]
     L.fs_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
     L.fs_set_arrival_limits.argtypes = [vp, dbl, dbl]
     L.fs_score_arrival.argtypes = [vp, i32] + [vp] * 10
@@ -215,6 +226,20 @@ class FrontierScorer:
         n = C.c_int64()
         self._check(self._L.fs_frontier_cells(self._h, int(lethal_threshold), _p(mask), C.byref(n)))
         return mask, n.value
+
+    def frontier_clusters(self, shape_yx, robot_xy, lethal_threshold=160, max_frontier_distance=50.0, max_frontier_cluster_size=20,
+                          max_clusters=65536, want_labels=True):
+        """FrontierSearch::searchFrom as clusters: returns (labels [ny][nx] or None, clusters (CLUSTER_DTYPE, ascending label),
+        n_clusters, n_cells)."""
+        ny, nx = shape_yx[-2], shape_yx[-1]
+        labels = np.zeros((ny, nx), dtype=np.int32) if want_labels else None
+        cl = np.zeros(max_clusters, dtype=CLUSTER_DTYPE)
+        n, cells = C.c_int32(), C.c_int64()
+        xy = (C.c_double * 2)(float(robot_xy[0]), float(robot_xy[1]))
+        self._check(self._L.fs_frontier_clusters(self._h, C.byref(xy), int(lethal_threshold), float(max_frontier_distance),
+                                                 int(max_frontier_cluster_size), _p(labels), int(max_clusters), _p(cl),
+                                                 C.byref(n), C.byref(cells)))
+        return labels, cl[:min(n.value, max_clusters)].copy(), n.value, cells.value
 
     def max_arrival(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()

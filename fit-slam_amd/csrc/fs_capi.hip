@@ -129,6 +129,12 @@ struct fs_ctx {
     DevBuf<uint8_t> d_seg_ok, d_seg_hit, d_mask, d_brick_cells;
     DevBuf<int32_t> d_seg_traced, d_seg_unknown, d_seg_all, d_brick_xyz, d_bad;
     DevBuf<unsigned long long> d_count;
+    // fs_frontier_clusters
+    DevBuf<int32_t> d_fc_parent_t, d_fc_parent_f, d_fc_aux, d_fc_state, d_fc_labels;
+    DevBuf<uint32_t> d_fc_queue;
+    DevBuf<uint8_t> d_fc_visited;
+    DevBuf<fs_frontier_cluster> d_fc_clusters;
+    DevBuf<long long> d_fc_sums;
     bool opt_sort = true;
     int opt_layout = 0;            // 0 auto, 1 row-major walk, 2 bricked walk, 3 LDS-staged fan (planar fans; else auto)
 
@@ -546,6 +552,8 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_seg_start.release(); c->d_seg_end.release(); c->d_tri.release(); c->d_seg_ok.release(); c->d_seg_hit.release();
     c->d_mask.release(); c->d_brick_cells.release(); c->d_seg_traced.release(); c->d_seg_unknown.release();
     c->d_seg_all.release(); c->d_brick_xyz.release(); c->d_bad.release(); c->d_count.release();
+    c->d_fc_parent_t.release(); c->d_fc_parent_f.release(); c->d_fc_aux.release(); c->d_fc_state.release(); c->d_fc_labels.release();
+    c->d_fc_queue.release(); c->d_fc_visited.release(); c->d_fc_clusters.release(); c->d_fc_sums.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -741,6 +749,62 @@ int fs_frontier_cells(fs_ctx *c, int32_t lethal_threshold, uint8_t *mask, int64_
     if (mask) FS_HIP(c, hipMemcpyAsync(mask, d_mask.p, total, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
     *count = (int64_t)n;
+    return FS_OK;
+}
+
+int fs_frontier_clusters(fs_ctx *c, const double robot_xy[2], int32_t lethal_threshold, double max_frontier_distance,
+                         int32_t max_frontier_cluster_size, int32_t *labels, int32_t max_clusters,
+                         fs_frontier_cluster *clusters, int32_t *n_clusters, int64_t *n_cells)
+{
+    if (!c || !robot_xy || !n_clusters || max_clusters < 0 || (max_clusters > 0 && !clusters)) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
+    if (c->nz != 1) return fail(c, FS_E_INVALID, "the frontier search is defined on a 2-D costmap (nz == 1)");
+    *n_clusters = 0;
+    if (n_cells) *n_cells = 0;
+    const size_t cells = (size_t)c->nx * c->ny;
+    // :26-33 — worldToMap of the robot position; off the map: no frontiers
+    const double px = robot_xy[0], py = robot_xy[1];
+    bool on_map = !(px < c->origin[0] || py < c->origin[1]);
+    unsigned int mx = 0, my = 0;
+    if (on_map) {
+        const double qx = (px - c->origin[0]) / c->res, qy = (py - c->origin[1]) / c->res;
+        on_map = qx < 4294967296.0 && qy < 4294967296.0;
+        if (on_map) {
+            mx = static_cast<unsigned int>(qx); my = static_cast<unsigned int>(qy);
+            on_map = mx < (unsigned int)c->nx && my < (unsigned int)c->ny;
+        }
+    }
+    if (!on_map) {
+        if (labels) std::fill(labels, labels + cells, -1);
+        return FS_OK;
+    }
+    FS_HIP(c, c->d_fc_parent_t.ensure(cells)); FS_HIP(c, c->d_fc_parent_f.ensure(cells)); FS_HIP(c, c->d_fc_aux.ensure(cells));
+    FS_HIP(c, c->d_fc_queue.ensure(cells)); FS_HIP(c, c->d_fc_visited.ensure(cells)); FS_HIP(c, c->d_fc_state.ensure(8));
+    if (labels) FS_HIP(c, c->d_fc_labels.ensure(cells));
+    FS_HIP(c, c->d_fc_clusters.ensure((size_t)std::max(max_clusters, 1))); FS_HIP(c, c->d_fc_sums.ensure(2 * (size_t)std::max(max_clusters, 1)));
+    const double reach = max_frontier_distance + (max_frontier_cluster_size * c->res * 1.414);      // :67
+    {
+        ScopedTimer t(c, 5);
+        FS_HIP(c, fs_launch_frontier_clusters(c->d_cells.p, c->nx, c->ny, c->origin[0], c->origin[1], c->res, px, py,
+                                              (int32_t)(my * (unsigned int)c->nx + mx), reach, lethal_threshold,
+                                              c->d_fc_parent_t.p, c->d_fc_parent_f.p, c->d_fc_aux.p, c->d_fc_queue.p, c->d_fc_visited.p,
+                                              c->d_fc_state.p, labels ? c->d_fc_labels.p : nullptr, max_clusters, c->d_fc_clusters.p,
+                                              c->d_fc_sums.p, c->stream));
+    }
+    int32_t state[8];
+    FS_HIP(c, hipMemcpyAsync(state, c->d_fc_state.p, sizeof state, hipMemcpyDeviceToHost, c->stream));
+    if (labels) FS_HIP(c, hipMemcpyAsync(labels, c->d_fc_labels.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    const int32_t stored = std::min(state[5], max_clusters);
+    if (stored > 0) {
+        FS_HIP(c, hipMemcpyAsync(clusters, c->d_fc_clusters.p, sizeof(fs_frontier_cluster) * (size_t)stored, hipMemcpyDeviceToHost, c->stream));
+        FS_HIP(c, hipStreamSynchronize(c->stream));
+        // slots were handed out in arrival order: present the clusters by ascending label
+        std::sort(clusters, clusters + stored, [](const fs_frontier_cluster &u, const fs_frontier_cluster &v) { return u.label < v.label; });
+    }
+    *n_clusters = state[5];
+    if (n_cells) *n_cells = state[6];
     return FS_OK;
 }
 

@@ -1,0 +1,240 @@
+// fs_frontier.hip — frontier detection + clustering on the GPU, gfx950.
+//
+// Replaces the two nested breadth-first searches of FrontierSearch::searchFrom / buildNewFrontier
+// (DEP/src/FrontierSearch.cpp:21-216) by order-independent set operations that give the same cells in the same clusters:
+//   E  = the cells the outer search EXPANDS: the start cell plus every cell with cost < LETHAL_OBSTACLE (254) that lies
+//        within the search radius and is 4-connected, through such cells, to a neighbour of the start cell (:59-73)
+//   F  = the frontier cells (isNewFrontierCell, :218-249): unknown, no lethal 4-neighbour, at least one free one
+//   a frontier cell 4-adjacent to a cell of E seeds buildNewFrontier (:75-78), which collects the whole 8-connected
+//   component of F around it (:119-143) — so the search finds exactly the 8-connected components of F that touch E.
+// Both connectivity problems are solved with a lock-free union-find over the cell array (roots = smallest cell index
+// of a component: a canonical label), three passes over the grid each, instead of a serial queue.  The start cell is
+// nearestFreeCell's (DEP/src/Helpers.cpp:285-329) — an exact single-lane emulation of its queue, which ends at once in
+// the normal case of a robot standing on a free cell.  What is NOT reproduced is order-dependent by construction in the
+// reference: cutting a component into pieces of max_frontier_cluster_size + 1 cells in queue order (:146-178) and the
+// angular-median goal point of each piece (:158-170); the number and sizes of the pieces follow from a component's
+// size, and are reported as such (fs_frontier_cluster::size).
+#include "fs_internal.h"
+
+namespace {
+
+// (agent-scope loads: links written by other CUs' atomics live in L2, a CU's L1 is never refreshed by them)
+__device__ __forceinline__ int uf_find(const int32_t *parent, int x)
+{
+    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) { x = p; p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return x;
+}
+
+// link the larger root under the smaller one; roots only ever decrease, so the smallest index of a component ends up its root
+__device__ __forceinline__ void uf_union(int32_t *parent, int a, int b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&parent[b], a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+struct FcArgs {
+    const uint8_t *map;
+    int32_t nx, ny;
+    double ox, oy, res;
+    double px, py;              // robot position
+    double reach;               // max_frontier_distance + max_frontier_cluster_size * resolution * 1.414 (:67)
+    int32_t lethal_threshold;
+    int32_t *parent_t, *parent_f, *aux;
+    int32_t *state;             // [8]: 0 start cell, 1..4 roots of the start cell's expanded neighbours (-1: none), 5 clusters found, 6 cells found
+};
+
+// per cell: is it expandable (T) / a frontier cell (F)?  parent arrays start as singletons (or -1 outside the set)
+__global__ void fs_fc_classify_kernel(const FcArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nx * a.ny) return;
+    const int y = i / a.nx, x = i - y * a.nx;
+    const int c = a.map[i];
+    // :62-68 — cost below LETHAL_OBSTACLE and inside the search radius (same fp64 expression: mapToWorld, pow(.,2), sqrt)
+    const double wx = a.ox + (x + 0.5) * a.res, wy = a.oy + (y + 0.5) * a.res;
+    const double dx = a.px - wx, dy = a.py - wy;
+    const bool t = c < 254 && sqrt(dx * dx + dy * dy) < a.reach;
+    bool f = false;
+    if (c == 255) {                                                         // :221
+        bool has_free = false, has_lethal = false;
+        auto look = [&](int j) {
+            const int v = a.map[j];
+            if (v < a.lethal_threshold) has_free = true;                    // isFree
+            if (v >= a.lethal_threshold && v != 255) has_lethal = true;     // isLethal
+        };
+        if (x > 0) look(i - 1);
+        if (x < a.nx - 1) look(i + 1);
+        if (y > 0) look(i - a.nx);
+        if (y < a.ny - 1) look(i + a.nx);
+        f = !has_lethal && has_free;                                        // :241-246
+    }
+    a.parent_t[i] = t ? i : -1;
+    a.parent_f[i] = f ? i : -1;
+    a.aux[i] = -1;
+}
+
+// forward neighbours only (each pair once): right, down (4-connected T); + down-left, down-right (8-connected F)
+__global__ void fs_fc_union_kernel(const FcArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nx * a.ny) return;
+    const int y = i / a.nx, x = i - y * a.nx;
+    const bool right = x < a.nx - 1, down = y < a.ny - 1, left = x > 0;
+    if (a.parent_t[i] >= 0) {
+        if (right && a.parent_t[i + 1] >= 0) uf_union(a.parent_t, i, i + 1);
+        if (down && a.parent_t[i + a.nx] >= 0) uf_union(a.parent_t, i, i + a.nx);
+    }
+    if (a.parent_f[i] >= 0) {
+        if (right && a.parent_f[i + 1] >= 0) uf_union(a.parent_f, i, i + 1);
+        if (down && a.parent_f[i + a.nx] >= 0) uf_union(a.parent_f, i, i + a.nx);
+        if (down && left && a.parent_f[i + a.nx - 1] >= 0) uf_union(a.parent_f, i, i + a.nx - 1);
+        if (down && right && a.parent_f[i + a.nx + 1] >= 0) uf_union(a.parent_f, i, i + a.nx + 1);
+    }
+}
+
+__global__ void fs_fc_flatten_kernel(const FcArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nx * a.ny) return;
+    if (a.parent_t[i] >= 0) a.parent_t[i] = uf_find(a.parent_t, i);
+    if (a.parent_f[i] >= 0) a.parent_f[i] = uf_find(a.parent_f, i);
+}
+
+// One lane: the start cell of the outer search (:44-54) and the components of T its neighbours expand into.
+// nearestFreeCell is emulated with its own queue (in `queue`, visited flags in `visited`): first cell in queue order
+// with cost < (unsigned char)lethal_threshold.
+__global__ void fs_fc_start_kernel(const FcArgs a, int32_t pos, uint32_t *queue, uint8_t *visited)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int n = a.nx * a.ny;
+    const int val = a.lethal_threshold & 0xff;                              // the parameter is an unsigned char (Helpers.hpp:141)
+    int start = pos;
+    if (!(a.map[pos] < val)) {
+        uint32_t head = 0, tail = 0;
+        queue[tail++] = (uint32_t)pos;
+        visited[pos] = 1;
+        bool found = false;
+        while (head < tail) {
+            const int idx = (int)queue[head++];
+            if (a.map[idx] < val) { start = idx; found = true; break; }
+            const int y = idx / a.nx, x = idx - y * a.nx;
+            const bool l = x > 0, r = x < a.nx - 1, u = y > 0, d = y < a.ny - 1;
+            // nhood8's order (Helpers.cpp:199-252): -1, +1, -nx, +nx, -1-nx, -1+nx, +1-nx, +1+nx
+            const int nb[8] = {l ? idx - 1 : -1, r ? idx + 1 : -1, u ? idx - a.nx : -1, d ? idx + a.nx : -1,
+                               (l && u) ? idx - 1 - a.nx : -1, (l && d) ? idx - 1 + a.nx : -1,
+                               (r && u) ? idx + 1 - a.nx : -1, (r && d) ? idx + 1 + a.nx : -1};
+            for (int k = 0; k < 8; ++k) {
+                const int j = nb[k];
+                if (j >= 0 && j < n && !visited[j]) { queue[tail++] = (uint32_t)j; visited[j] = 1; }
+            }
+        }
+        if (!found) start = pos;                                            // :51-54
+    }
+    a.state[0] = start;
+    const int y = start / a.nx, x = start - y * a.nx;
+    const int nb[4] = {x > 0 ? start - 1 : -1, x < a.nx - 1 ? start + 1 : -1, y > 0 ? start - a.nx : -1, y < a.ny - 1 ? start + a.nx : -1};
+    for (int k = 0; k < 4; ++k) a.state[1 + k] = (nb[k] >= 0 && a.parent_t[nb[k]] >= 0) ? a.parent_t[nb[k]] : -1;
+    a.state[5] = 0;
+    a.state[6] = 0;
+}
+
+__device__ __forceinline__ bool fc_expanded(const FcArgs &a, int j)
+{
+    if (j == a.state[0]) return true;
+    const int r = a.parent_t[j];
+    return r >= 0 && (r == a.state[1] || r == a.state[2] || r == a.state[3] || r == a.state[4]);
+}
+
+// a frontier cell next to an expanded cell marks its component as found (aux[root] = 0)
+__global__ void fs_fc_seed_kernel(const FcArgs a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nx * a.ny) return;
+    const int root = a.parent_f[i];
+    if (root < 0) return;
+    const int y = i / a.nx, x = i - y * a.nx;
+    const bool seed = (x > 0 && fc_expanded(a, i - 1)) || (x < a.nx - 1 && fc_expanded(a, i + 1)) ||
+                      (y > 0 && fc_expanded(a, i - a.nx)) || (y < a.ny - 1 && fc_expanded(a, i + a.nx));
+    if (seed) a.aux[root] = 0;
+}
+
+// found roots get a dense cluster slot
+__global__ void fs_fc_enumerate_kernel(const FcArgs a, int32_t max_clusters, fs_frontier_cluster *clusters, long long *sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nx * a.ny) return;
+    if (a.parent_f[i] != i || a.aux[i] != 0) return;
+    const int slot = atomicAdd(&a.state[5], 1);
+    a.aux[i] = slot < max_clusters ? slot + 1 : -2;                         // slot + 1 (> 0), or -2: no room in the caller's array
+    if (slot < max_clusters) {
+        fs_frontier_cluster c;
+        c.label = i; c.size = 0; c.centroid_x = 0.0; c.centroid_y = 0.0;
+        c.min_x = a.nx; c.min_y = a.ny; c.max_x = -1; c.max_y = -1;
+        clusters[slot] = c;
+        sums[2 * slot] = 0; sums[2 * slot + 1] = 0;
+    }
+}
+
+__global__ void fs_fc_collect_kernel(const FcArgs a, int32_t *labels, fs_frontier_cluster *clusters, long long *sums)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.nx * a.ny) return;
+    const int root = a.parent_f[i];
+    int label = -1;
+    if (root >= 0 && a.aux[root] != -1 && a.aux[root] != 0) {
+        label = root;
+        atomicAdd(&a.state[6], 1);
+        const int slot = a.aux[root] - 1;
+        if (slot >= 0) {
+            const int y = i / a.nx, x = i - y * a.nx;
+            atomicAdd(&clusters[slot].size, 1);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sums[2 * slot]), (unsigned long long)x);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&sums[2 * slot + 1]), (unsigned long long)y);
+            atomicMin(&clusters[slot].min_x, x); atomicMin(&clusters[slot].min_y, y);
+            atomicMax(&clusters[slot].max_x, x); atomicMax(&clusters[slot].max_y, y);
+        }
+    }
+    if (labels) labels[i] = label;
+}
+
+// centroid of the cell centres (mapToWorld of the mean index: exact integer sums, one division)
+__global__ void fs_fc_finish_kernel(const FcArgs a, int32_t n, fs_frontier_cluster *clusters, const long long *sums)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || k >= a.state[5]) return;
+    const double inv = 1.0 / (double)clusters[k].size;
+    clusters[k].centroid_x = a.ox + ((double)sums[2 * k] * inv + 0.5) * a.res;
+    clusters[k].centroid_y = a.oy + ((double)sums[2 * k + 1] * inv + 0.5) * a.res;
+}
+
+}  // namespace
+
+// scratch: parent_t, parent_f, aux [cells] int32; queue [cells] uint32; visited [cells] uint8; state [8] int32; sums [2 * max_clusters] int64
+hipError_t fs_launch_frontier_clusters(const uint8_t *d_map, int nx, int ny, double ox, double oy, double res, double px, double py,
+                                       int32_t start_pos, double reach, int32_t lethal_threshold, int32_t *d_parent_t, int32_t *d_parent_f,
+                                       int32_t *d_aux, uint32_t *d_queue, uint8_t *d_visited, int32_t *d_state, int32_t *d_labels,
+                                       int32_t max_clusters, fs_frontier_cluster *d_clusters, long long *d_sums, hipStream_t s)
+{
+    FcArgs a{d_map, nx, ny, ox, oy, res, px, py, reach, lethal_threshold, d_parent_t, d_parent_f, d_aux, d_state};
+    const int n = nx * ny;
+    const dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(fs_fc_classify_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(fs_fc_union_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(fs_fc_flatten_kernel, grid, block, 0, s, a);
+    hipError_t e = hipMemsetAsync(d_visited, 0, (size_t)n, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fs_fc_start_kernel, dim3(1), dim3(64), 0, s, a, start_pos, d_queue, d_visited);
+    hipLaunchKernelGGL(fs_fc_seed_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(fs_fc_enumerate_kernel, grid, block, 0, s, a, max_clusters, d_clusters, d_sums);
+    hipLaunchKernelGGL(fs_fc_collect_kernel, grid, block, 0, s, a, d_labels, d_clusters, d_sums);
+    if (max_clusters > 0) hipLaunchKernelGGL(fs_fc_finish_kernel, dim3((max_clusters + 255) / 256), block, 0, s, a, max_clusters, d_clusters, d_sums);
+    return hipGetLastError();
+}

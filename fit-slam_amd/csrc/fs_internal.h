@@ -82,6 +82,11 @@ hipError_t fs_launch_frontier_pair(int n, const float *lx, const float *ly, cons
 hipError_t fs_launch_frontier_cells(const uint8_t *d_grid, int nx, int ny, int nz, int lethal_threshold, uint8_t *d_mask,
                                     unsigned long long *d_count, hipStream_t s);
 
+hipError_t fs_launch_frontier_clusters(const uint8_t *d_map, int nx, int ny, double ox, double oy, double res, double px, double py,
+                                       int32_t start_pos, double reach, int32_t lethal_threshold, int32_t *d_parent_t, int32_t *d_parent_f,
+                                       int32_t *d_aux, uint32_t *d_queue, uint8_t *d_visited, int32_t *d_state, int32_t *d_labels,
+                                       int32_t max_clusters, fs_frontier_cluster *d_clusters, long long *d_sums, hipStream_t s);
+
 // ---- key-frame pose information (computeInformationForPose)
 struct FsKfArgs {
     int32_t n;                 // poses

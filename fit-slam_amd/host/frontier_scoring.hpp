@@ -8,6 +8,7 @@
 //   frontier_exploration::Frontier / FrontierPtr    <- DEP/include/frontier_exploration/Frontier.hpp:39-134
 //   frontier_exploration::FrontierCostCalculator    <- DEP/include/.../CostCalculator.hpp:46-136, DEP/src/CostCalculator.cpp:5-191,512-520
 //   frontier_exploration::FrontierCostsManager      <- DEP/src/FrontierCostsManager.cpp:47-223
+//   frontier_exploration::FrontierSearch             <- DEP/include/.../FrontierSearch.hpp:31-127, DEP/src/FrontierSearch.cpp:21-216 (clusters)
 //   frontier_exploration::CostAssigner (+ Request/Response) <- DEP/include/.../CostAssigner.hpp:43-100, DEP/src/CostAssigner.cpp:29-167
 //   frontier_exploration_information_affine::computeInformationForPose <- DEP/include/.../deprecated/util.hpp:840-916 (batched)
 //   roadmap_explorer::FisherInformationManager      <- FIP/include/.../FisherInfoManager.hpp:72-145, FIP/src/.../FisherInfoManager.cpp:31-324
@@ -444,6 +445,76 @@ inline std::vector<bool> isConnectable(ScoringContext &ctx, const Costmap2D &cos
         out[i] = ok[i] && !hit[i] && !(unknown[i] > radius_to_decide_edges / costmap.getResolution() * 0.3);
     return out;
 }
+
+// DEP/include/.../FrontierSearch.hpp:31-127 — the producer of the candidate list.  searchFrom's two nested breadth-first
+// searches become ONE fs_frontier_clusters call; what comes back is the 8-connected component structure the reference's
+// queues walk (same cells, same clusters).  The reference then cuts a cluster into pieces of max_frontier_cluster_size + 1
+// cells in queue order and takes an angular median as each piece's goal (FrontierSearch.cpp:146-205): steps that depend
+// on the order of its queue by construction, left to the caller on the cell lists returned here.
+class FrontierSearch
+{
+public:
+    struct Cluster
+    {
+        int label = -1, size = 0;                       // label: smallest cell index of the component
+        Point centroid;                                 // mean of the cell centres (mapToWorld)
+        std::vector<std::pair<double, double>> cells;   // cell centres, ascending cell index (frontier_cell_indices' content)
+    };
+    FrontierSearch(std::shared_ptr<ScoringContext> ctx, std::shared_ptr<Costmap2D> costmap, int min_frontier_cluster_size = 1,
+                   int max_frontier_cluster_size = 20, double max_frontier_distance = 50.0, int lethal_threshold = 160)
+        : ctx_(std::move(ctx)), costmap_(std::move(costmap)), min_frontier_cluster_size_(min_frontier_cluster_size),
+          max_frontier_cluster_size_(max_frontier_cluster_size), max_frontier_distance_(max_frontier_distance),
+          original_search_distance_(max_frontier_distance), lethal_threshold_(lethal_threshold) {}
+    void reset() { every_frontier_list.clear(); }
+    void incrementSearchDistance(double value) { max_frontier_distance_ += value; }
+    void resetSearchDistance() { max_frontier_distance_ = original_search_distance_; }
+    std::vector<std::vector<double>> getAllFrontiers() { return every_frontier_list; }
+
+    // FrontierSearch.cpp:21-96 up to the clusters; the grid must have been staged (FrontierCostCalculator::updateCostmap)
+    std::vector<Cluster> searchFrom(Point position)
+    {
+        const unsigned int nx = costmap_->getSizeInCellsX(), ny = costmap_->getSizeInCellsY();
+        std::vector<int32_t> labels((size_t)nx * ny);
+        std::vector<fs_frontier_cluster> raw((size_t)nx * ny / 2 + 1);
+        int32_t n = 0;
+        int64_t n_cells = 0;
+        const double xy[2] = {position.x, position.y};
+        ctx_->check(fs_frontier_clusters(ctx_->get(), xy, lethal_threshold_, max_frontier_distance_, max_frontier_cluster_size_,
+                                         labels.data(), (int32_t)raw.size(), raw.data(), &n, &n_cells), "fs_frontier_clusters");
+        std::vector<Cluster> out((size_t)n);
+        std::unordered_map<int, size_t> slot;
+        for (int32_t k = 0; k < n; ++k) {
+            out[k].label = raw[k].label; out[k].size = raw[k].size;
+            out[k].centroid.x = raw[k].centroid_x; out[k].centroid.y = raw[k].centroid_y;
+            slot[raw[k].label] = (size_t)k;
+        }
+        for (unsigned int idx = 0; idx < nx * ny; ++idx) {
+            if (labels[idx] < 0) continue;
+            unsigned int mx, my;
+            double wx, wy;
+            costmap_->indexToCells(idx, mx, my);
+            costmap_->mapToWorld(mx, my, wx, wy);
+            out[slot[labels[idx]]].cells.emplace_back(wx, wy);
+            every_frontier_list.push_back({wx, wy});
+        }
+        return out;
+    }
+    // sizes of the Frontier records buildNewFrontier emits for a cluster of n cells (FrontierSearch.cpp:146-205, :81)
+    std::vector<int> pieceSizes(int n) const
+    {
+        std::vector<int> out(n / (max_frontier_cluster_size_ + 1), max_frontier_cluster_size_ + 1);
+        if (n % (max_frontier_cluster_size_ + 1) > min_frontier_cluster_size_) out.push_back(n % (max_frontier_cluster_size_ + 1));
+        return out;
+    }
+
+private:
+    std::shared_ptr<ScoringContext> ctx_;
+    std::shared_ptr<Costmap2D> costmap_;
+    int min_frontier_cluster_size_, max_frontier_cluster_size_;
+    double max_frontier_distance_, original_search_distance_;
+    int lethal_threshold_;
+    std::vector<std::vector<double>> every_frontier_list;
+};
 
 // DEP/include/.../CostAssigner.hpp:43-59
 struct GetFrontierCostsRequest

@@ -131,6 +131,22 @@ int main(int argc, char **argv)
         if (connectable.size() != (size_t)n) ++failures;
     }
 
+    // FrontierSearch::searchFrom from the start pose: clusters, their cells and the piece sizes the reference would emit
+    size_t fs_clusters = 0, fs_cells = 0, fs_pieces = 0;
+    {
+        FrontierSearch search(ctx, costmap);
+        Point robot; robot.x = start[0]; robot.y = start[1];
+        const auto clusters = search.searchFrom(robot);
+        fs_clusters = clusters.size();
+        for (const auto &cl : clusters) {
+            if ((size_t)cl.size != cl.cells.size()) ++failures;
+            fs_cells += cl.cells.size();
+            for (int piece : search.pieceSizes(cl.size)) fs_pieces += (piece > 0);
+        }
+        if (search.getAllFrontiers().size() != fs_cells) ++failures;
+        printf("FrontierSearch: %zu clusters, %zu cells, %zu pieces\n", fs_clusters, fs_cells, fs_pieces);
+    }
+
     // error behaviour of the reference interface
     failures += expect_throw("Frontier getter on unset field", [] { Frontier fr; (void)fr.getArrivalInformation(); });
     failures += expect_throw("duplicate frontiers", [&] {
@@ -156,6 +172,8 @@ int main(int argc, char **argv)
                                 res_->frontier_distances[i], (double)info[i], (double)kf_info[i], (double)connectable[i]};
         fwrite(row, sizeof(double), 10, o);
     }
+    const double tail[3] = {(double)fs_clusters, (double)fs_cells, (double)fs_pieces};
+    fwrite(tail, sizeof(double), 3, o);
     fclose(o);
     printf("failures: %d\n", failures);
     return failures ? 1 : 0;

@@ -152,6 +152,29 @@ int fs_upload_grid_bricks(fs_ctx *ctx, int32_t nx, int32_t ny, int32_t nz, const
  * reference (searchFrom / buildNewFrontier) consumes this mask on the host. */
 int fs_frontier_cells(fs_ctx *ctx, int32_t lethal_threshold, uint8_t *mask, int64_t *count);
 
+/* Frontier detection + clustering (second half).  Replaces, for a 2-D costmap (nz == 1),
+ * std::vector<FrontierPtr> FrontierSearch::searchFrom(geometry_msgs::msg::Point position) (DEP/include/.../FrontierSearch.hpp:62,
+ * DEP/src/FrontierSearch.cpp:21-96) with buildNewFrontier (:98-216), nearestFreeCell (DEP/src/Helpers.cpp:285-329) and
+ * isNewFrontierCell (:218-249): the frontier cells the search collects — the 8-connected components of the frontier-cell
+ * set that touch the region the outer search expands from the robot (cost < 254, within max_frontier_distance +
+ * max_frontier_cluster_size * resolution * 1.414) — as clusters.
+ *   labels   [ny][nx] or NULL: -1, or the cluster's label = the smallest cell index (y * nx + x) of its component
+ *   clusters [max_clusters], ascending label; *n_clusters = clusters found (may exceed max_clusters: the first ones by label are
+ *            stored); *n_cells = frontier cells found = every_frontier_list.size() of the reference
+ * The reference then cuts a component into pieces of max_frontier_cluster_size + 1 cells in the order of its queue and takes
+ * an angular median as each piece's goal point (:146-205): order-dependent steps that stay with the caller; a component of
+ * `size` cells yields size / (max + 1) full pieces and, if size % (max + 1) > min_frontier_cluster_size, one more.
+ * A robot position off the map gives no cluster (:28-33). */
+typedef struct {
+    int32_t label;               /* smallest cell index of the component */
+    int32_t size;                /* cells in the component */
+    double  centroid_x, centroid_y;   /* mean of the cell centres (mapToWorld), world frame */
+    int32_t min_x, min_y, max_x, max_y;   /* bounding box in cells */
+} fs_frontier_cluster;
+int fs_frontier_clusters(fs_ctx *ctx, const double robot_xy[2], int32_t lethal_threshold, double max_frontier_distance,
+                         int32_t max_frontier_cluster_size, int32_t *labels, int32_t max_clusters,
+                         fs_frontier_cluster *clusters, int32_t *n_clusters, int64_t *n_cells);
+
 /* Replaces double FrontierCostCalculator::setMaxArrivalInformation() (DEP/include/.../CostCalculator.hpp:58,
  * DEP/src/CostCalculator.cpp:123-191): geometric maximum of the FOV window on an obstacle-free fan from
  * world (0,0).  max_value = the window maximum (0 if (0,0) is off-map: limits stay unset, as the

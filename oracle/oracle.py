@@ -20,7 +20,7 @@ STATUS_OK, STATUS_OFF_MAP, STATUS_BLACKLISTED = 0, 1, 2
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("fso_raycast.c", "fso_fisher.c", "fso_oracle.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("fso_raycast.c", "fso_fisher.c", "fso_frontier.cpp", "fso_oracle.h", "Makefile")]
     stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
@@ -478,3 +478,35 @@ def frontier_cell_mask(cells, lethal_threshold=160):
         out[:, :-1, :] |= m[:, 1:, :]
         return out
     return (unknown & ~any_nb(lethal) & any_nb(free)).astype(np.uint8)
+
+
+def frontier_search(cells2d, origin, resolution, position_xy, lethal_threshold=160, min_cluster=1, max_cluster=20,
+                    max_distance=50.0):
+    """FrontierSearch::searchFrom (DEP/src/FrontierSearch.cpp:21-216) on a 2-D costmap — oracle/fso_frontier.cpp.
+    Returns dict(ok, goals [k][2], sizes [k], piece [k], cell_piece [ny][nx], cell_seed [ny][nx], n_every):
+    the emitted Frontier records in output order; per cell the sequence number of the piece it was collected into and the
+    seed cell of its buildNewFrontier call (-1: not a found frontier cell)."""
+    c = np.ascontiguousarray(cells2d, dtype=np.uint8)
+    if c.ndim == 3:
+        assert c.shape[0] == 1
+        c = c[0]
+    ny, nx = c.shape
+    cell_piece = np.zeros((ny, nx), dtype=np.int32)
+    cell_seed = np.zeros((ny, nx), dtype=np.int32)
+    cap = ny * nx
+    goals = np.zeros((cap, 2), dtype=np.float64)
+    sizes = np.zeros(cap, dtype=np.int32)
+    piece = np.zeros(cap, dtype=np.int32)
+    n_out = C.c_int32()
+    n_every = C.c_int64()
+    f = lib().fso_frontier_search
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                  C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    ok = f(_p(c), nx, ny, float(origin[0]), float(origin[1]), float(resolution), float(position_xy[0]), float(position_xy[1]),
+           int(lethal_threshold), int(min_cluster), int(max_cluster), float(max_distance), _p(cell_piece), _p(cell_seed),
+           cap, _p(goals), _p(sizes), _p(piece), C.byref(n_out), C.byref(n_every))
+    k = n_out.value
+    return dict(ok=bool(ok), goals=goals[:k].copy(), sizes=sizes[:k].copy(), piece=piece[:k].copy(),
+                cell_piece=cell_piece, cell_seed=cell_seed, n_every=int(n_every.value))
