@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--skip-calib", action="store_true")
     ap.add_argument("--skip-stats", action="store_true")
     ap.add_argument("--passes", default=",".join(SQ_PASSES))
+    ap.add_argument("--bench-arg", action="append", default=[], help="extra argument for bench.py (repeatable), e.g. --bench-arg=--option --bench-arg=ray.layout=2")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
@@ -131,6 +132,7 @@ def main():
     bench = ["python3", os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--cpu-seconds", "0", "--no-parity"]
     if args.depth_cells:
         bench += ["--depth-cells", str(args.depth_cells)]
+    bench += args.bench_arg
     summary = {"source_hash": source_hash(), "workload": args.workload, "depth_cells": args.depth_cells,
                "collected_with": "tools/pmc_collect.py: rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- "
                                  "python3 bench.py --steps 3 --warmup 2 --repeats 2 --cpu-seconds 0 --no-parity; means over the last 6 dispatches",
@@ -188,12 +190,17 @@ def main():
     summary["kernels"] = per_kernel
     summary["calibration"] = calib
     # peak VALU issue rate of one SIMD, wave-instructions per cycle: from the calibration kernel's own s_memtime (W >= 2)
-    peak = None
+    # A SIMD arbitrates oldest-first, so the waves of one SIMD finish at very different times; what the SIMD sustains is
+    # set by the LAST wave: W waves x insts / slowest wave's cycles.
+    peak = peak4 = None
     if calib.get("s_memtime"):
-        best = min(c["simd_cycles_per_wave_inst"] for c in calib["s_memtime"])
-        peak = 1.0 / best
+        per_w = {c["waves_per_simd"]: c["slowest_wave_cycles"] / (c["wave_insts"] * c["waves_per_simd"]) for c in calib["s_memtime"]}
+        peak = 1.0 / min(per_w.values())
+        peak4 = 1.0 / per_w[4] if 4 in per_w else None
         summary["valu_peak_wave_insts_per_cycle_per_simd"] = peak
-        summary["valu_simd_cycles_per_wave_inst"] = {str(c["waves_per_simd"]): c["simd_cycles_per_wave_inst"] for c in calib["s_memtime"]}
+        summary["valu_peak_at_4_waves_per_simd"] = peak4
+        summary["valu_simd_cycles_per_wave_inst"] = {str(w): v for w, v in sorted(per_w.items())}
+        summary["in_kernel_clock_ghz"] = {str(c["waves_per_simd"]): c.get("in_kernel_clock_ghz") for c in calib["s_memtime"]}
     fim = next((v for k, v in per_kernel.items() if k.startswith("fs_fim_kernel")), None)
     if fim:
         n_simd = 256 * 4
@@ -204,6 +211,8 @@ def main():
             if peak:
                 res["valu_issue_utilisation"] = res["valu_wave_insts_per_cycle_per_simd"] / peak
                 summary["valu_issue_utilisation"] = res["valu_issue_utilisation"]
+            if peak4:
+                res["valu_issue_utilisation_vs_4_wave_peak"] = res["valu_wave_insts_per_cycle_per_simd"] / peak4
         if cyc and "SQ_INSTS_SALU" in fim:
             res["salu_insts_per_cycle_per_cu"] = fim["SQ_INSTS_SALU"] / (256 * cyc)
         wc = fim.get("SQ_WAVE_CYCLES")
@@ -220,6 +229,24 @@ def main():
         if "TCC_HIT_sum" in fim:
             res["l2_hit_rate"] = fim["TCC_HIT_sum"] / max(1.0, fim["TCC_HIT_sum"] + fim.get("TCC_MISS_sum", 0.0))
         summary["fs_fim_kernel"] = res
+        u = res.get("valu_issue_utilisation")
+        w_any, w_inst = res.get("SQ_WAIT_ANY_share_of_wave_cycles"), res.get("SQ_WAIT_INST_ANY_share_of_wave_cycles")
+        hbm = summary.get("fs_fim_kernel_hbm_bytes_per_launch")
+        dur = res.get("duration_us")
+        if u is not None and w_any is not None:
+            if u >= 0.75:
+                summary["bound"] = "valu-issue"
+            elif w_any + (w_inst or 0.0) >= 0.5:
+                summary["bound"] = "latency (waves parked on LDS-atomic / barrier / load waits; 4 waves per SIMD)"
+            else:
+                summary["bound"] = "mixed"
+            summary["bound_evidence"] = (
+                f"fs_fim_kernel: VALU issue {u:.0%} of the SIMD peak measured by tools/valu_calib "
+                f"({summary['valu_peak_wave_insts_per_cycle_per_simd']:.3f} wave-insts/cycle/SIMD), waves parked {w_any:.0%} "
+                f"(SQ_WAIT_ANY) + issue-stalled {(w_inst or 0.0):.0%} (SQ_WAIT_INST_ANY) of their cycles"
+                + (f", L2 hit rate {res['l2_hit_rate']:.1%}" if "l2_hit_rate" in res else "")
+                + (f", HBM traffic {hbm / 1e6:.1f} MB per launch = {hbm / (dur * 1e-6) / 1e9:.0f} GB/s of 8000" if hbm and dur else "")
+                + ": not HBM-bound")
     json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True, default=dict)
     print(json.dumps({k: summary.get(k) for k in ("source_hash", "valu_peak_wave_insts_per_cycle_per_simd", "valu_issue_utilisation", "fs_fim_kernel",
                                                  "fs_fim_kernel_hbm_bytes_per_launch", "counters_missing", "failed_passes")}, indent=1, default=dict))

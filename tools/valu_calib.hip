@@ -19,51 +19,70 @@
 constexpr int kUnroll = 16;      // independent accumulators: no dependency stall at any issue rate
 constexpr int kIters = 4096;     // 65,536 v_fma_f32 per wave
 
-// 256-thread workgroups = one wave per SIMD; W workgroups per CU give W waves per SIMD (round-robin dispatch)
+// 256-thread workgroups = one wave per SIMD; W workgroups per CU give W waves per SIMD.  Placement is FORCED: every
+// workgroup claims 160 KiB / W of LDS (minus a margin), so exactly W of them fit a CU and a grid of 256 x W workgroups is
+// resident all at once, W per CU (the first version relied on round-robin dispatch and measured uneven SIMD loads).
 template <int W>
 __global__ __launch_bounds__(256) void valu_stream(float *out, unsigned long long *cycles, float a, float b)
 {
+    extern __shared__ float pin[];
+    if (a == 12345.f) pin[threadIdx.x] = b;                 // keep the allocation alive; never taken
     float acc[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) acc[u] = (float)(threadIdx.x + u);
-    unsigned long long t0, t1;
+    unsigned long long t0, t1, r0, r1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0) :: "memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory");
     for (int i = 0; i < kIters; ++i) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[u]) : "v"(a), "v"(b));
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1) :: "memory");
     float s = 0.f;
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) s += acc[u];
     out[blockIdx.x * 256 + threadIdx.x] = s;
-    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) {
+        cycles[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2] = t1 - t0;
+        cycles[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + 1] = r1 - r0;      // 100 MHz ticks
+    }
 }
 
 template <int W>
 int run(int cus, float *d_out, unsigned long long *d_cyc)
 {
     const int blocks = cus * W;
+    const size_t lds = (size_t)(160 * 1024) / W - 4096;     // W fit a CU, W + 1 do not (W = 1, 2, 4, 8)
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(valu_stream<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(valu_stream<W>), 256, lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(valu_stream<W>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 1.0001f, 0.5f);   // warm-up
+    hipLaunchKernelGGL(valu_stream<W>, dim3(blocks), dim3(256), lds, 0, d_out, d_cyc, 1.0001f, 0.5f);   // warm-up
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(valu_stream<W>, dim3(blocks), dim3(256), 0, 0, d_out, d_cyc, 1.0001f, 0.5f);
+    hipLaunchKernelGGL(valu_stream<W>, dim3(blocks), dim3(256), lds, 0, d_out, d_cyc, 1.0001f, 0.5f);
     CHECK(hipEventRecord(e1));
     CHECK(hipDeviceSynchronize());
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
-    std::vector<unsigned long long> cyc((size_t)blocks * 4);
-    CHECK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> both((size_t)blocks * 8);
+    CHECK(hipMemcpy(both.data(), d_cyc, both.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> cyc, real;
+    for (size_t i = 0; i < both.size(); i += 2) { cyc.push_back(both[i]); real.push_back(both[i + 1]); }
     std::sort(cyc.begin(), cyc.end());
+    std::sort(real.begin(), real.end());
     const double med = (double)cyc[cyc.size() / 2];
+    const double clock_ghz = med / ((double)real[real.size() / 2] * 10.0);        // cycles per ns
     const double insts = (double)kUnroll * kIters;
     // a wave gets 1/W of its SIMD: cycles the SIMD spends per wave-instruction = wave's cycles per instruction / W
     std::printf("{\"waves_per_simd\": %d, \"blocks\": %d, \"wave_insts\": %.0f, \"median_wave_cycles\": %.0f, "
                 "\"cycles_per_inst_per_wave\": %.3f, \"simd_cycles_per_wave_inst\": %.3f, \"kernel_ms\": %.4f, "
-                "\"chip_wave_insts_per_us\": %.1f}\n",
-                W, blocks, insts, med, med / insts, med / insts / W, ms, (double)blocks * 4 * insts / (ms * 1e3));
+                "\"chip_wave_insts_per_us\": %.1f, \"workgroups_per_cu_allowed\": %d, \"in_kernel_clock_ghz\": %.3f, "
+                "\"slowest_wave_cycles\": %.0f}\n",
+                W, blocks, insts, med, med / insts, med / insts / W, ms, (double)blocks * 4 * insts / (ms * 1e3), per_cu, clock_ghz,
+                (double)cyc.back());
     return 0;
 }
 
@@ -73,7 +92,7 @@ int main()
     CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     float *d_out; unsigned long long *d_cyc;
     CHECK(hipMalloc(&d_out, (size_t)cus * 8 * 256 * sizeof(float)));
-    CHECK(hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * sizeof(unsigned long long)));
+    CHECK(hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * 2 * sizeof(unsigned long long)));
     std::printf("{\"cus\": %d, \"s_memtime\": \"shader cycles\"}\n", cus);
     if (run<1>(cus, d_out, d_cyc)) return 1;
     if (run<2>(cus, d_out, d_cyc)) return 1;
