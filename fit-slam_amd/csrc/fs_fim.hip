@@ -443,9 +443,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         PoseLoad next_pose;                                        // in flight during this candidate's scoring loop
         if (nxt >= 0) next_pose = load_pose(nxt);
         if (tid == 0) sh_overflow[buf ^ 1] = 0;                    // flag of the candidate after this one
-        volatile int *v_overflow = &sh_overflow[buf];
+        // (the flag is read and written with workgroup-scope atomics on the LDS array itself: a `volatile int *` into it
+        // decays to a generic pointer, and FLAT accesses count on vmcnt — every read drained the landmark prefetch)
+        auto overflow_flag = [&]() -> int { return __hip_atomic_load(&sh_overflow[buf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        auto raise_overflow = [&]() { __hip_atomic_store(&sh_overflow[buf], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
         bool overflow = false;
-        if (skip_tier) { overflow = true; if (tid == 0) *v_overflow = 1; }
+        if (skip_tier) { overflow = true; if (tid == 0) raise_overflow(); }
 
         Acc acc;
         acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
@@ -460,7 +463,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (part > 0) {
             // next pass: everybody is done with the table -> clear it, restart the running voxel count
             __syncthreads();
-            const bool stop = __builtin_amdgcn_readfirstlane(*v_overflow) != 0;   // uniform: nobody writes the flag between these barriers
+            const bool stop = __builtin_amdgcn_readfirstlane(overflow_flag()) != 0;   // uniform: nobody writes the flag between these barriers
             uint4 *t4 = reinterpret_cast<uint4 *>(table);
             for (uint32_t i = tid; i < (slots >> 2); i += THREADS) t4[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
@@ -473,7 +476,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             unsigned long long mask = masks[g];
             mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
-            if (!GLOBAL_TABLE && __builtin_amdgcn_readfirstlane(*v_overflow)) break;   // another wave ran out of table: the HBM tier redoes it
+            if (!GLOBAL_TABLE && __builtin_amdgcn_readfirstlane(overflow_flag())) break;   // another wave ran out of table: the HBM tier redoes it
             auto pop = [&]() -> int {
                 if (!mask) return -1;
                 const int id = g0 + __builtin_ctzll(mask) * WAVES + wave;
@@ -521,7 +524,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                         st[8] += __builtin_readcyclecounter() - ts_; st[9] += 1;
 #endif
                         (void)opened;
-                        if (__any(overflow)) *v_overflow = 1;
+                        if (__any(overflow)) raise_overflow();
                     }
                 }
                 c0 = c1; x0 = x1; y0 = y1; z0 = z1;
@@ -535,7 +538,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
             qcount = 0;
         }
-        if (overflow) *v_overflow = 1;
+        if (overflow) raise_overflow();
         FS_STAMP(3);
         }   // passes
 
