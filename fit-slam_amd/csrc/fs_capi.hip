@@ -66,7 +66,8 @@ struct fs_ctx {
 
     // grid
     bool have_grid = false;
-    DevBuf<uint8_t> d_cells, d_bricks;    // dense row-major image and its 8x8x2-brick copy (FsGridDev)
+    DevBuf<uint8_t> d_cells, d_bricks, d_cells_t;   // dense row-major image, its 8x8x2-brick copy and its in-plane transpose (FsGridDev)
+    bool have_cells_t = false;                      // d_cells_t matches d_cells (built lazily: only "ray.layout" = 4 reads it)
     int32_t nx = 0, ny = 0, nz = 0;
     double origin[3] = {0, 0, 0};
     double res = 0.0;
@@ -136,7 +137,7 @@ struct fs_ctx {
     DevBuf<fs_frontier_cluster> d_fc_clusters;
     DevBuf<long long> d_fc_sums;
     bool opt_sort = true;
-    int opt_layout = 0;            // 0 auto, 1 row-major walk, 2 bricked walk, 3 LDS-staged fan (planar fans; else auto)
+    int opt_layout = 0;            // 0 auto, 1 row-major walk (a lane per ray), 2 bricked walk, 3 LDS-staged fan (planar fans; else auto), 4 span walk
 
     // timing
     bool timing = false;
@@ -373,7 +374,7 @@ int use_bricks(const fs_ctx *c, double max_length_cells)
 FsGridDev grid_dev(const fs_ctx *c)
 {
     return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res,
-                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3, c->d_counters.p + 29};
+                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3, c->d_counters.p + 29, c->d_cells_t.p};
 }
 
 // every upload path ends here: the ray kernels read the bricked copy
@@ -382,6 +383,7 @@ int retile_grid(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz)
     const size_t bytes = (size_t)((nx + 7) >> 3) * (size_t)((ny + 7) >> 3) * (size_t)((nz + 1) >> 1) * FS_BRICK_BYTES;
     FS_HIP(c, c->d_bricks.ensure(bytes));
     FS_HIP(c, fs_launch_retile(c->d_cells.p, c->d_bricks.p, nx, ny, nz, c->stream));
+    c->have_cells_t = false;                         // the transposed image (span walk only) is rebuilt on demand
     return FS_OK;
 }
 
@@ -407,6 +409,24 @@ int fill_ray_args(fs_ctx *c, FsRayArgs &a)
     // 20 k fans of 63 rays, L = 40; profiles/r02/ref2d_ray_layouts.json): row-major 0.065 ms, bricked
     // 0.084 ms, LDS-staged 0.081 ms — a 2-D map sits in L1/L2 and the kernel is bound by its per-fan set-up, so the
     // automatic choice stays the row-major walk and the LDS walk is only taken on request ("ray.layout" = 3).
+    // Span walk (fs_raymarch.hip, span_fan): 16 lanes take 16 consecutive steps of ONE ray, read from the image whose rows
+    // run along the ray's major axis.  Needs the fan's descriptors in LDS (32 B per ray) and step counts that keep the
+    // division-free Bresenham positions exact.
+    // Measured on C3 (profiles/r02/c3_span_walk.json): 0.499 ms against 0.228 ms for the lane-per-ray walk — the lines per
+    // load do drop, but every lane now evaluates its cell from scratch (two multiply-highs and five multiplies per
+    // group of 16 steps, quarter-rate integer ops) where the lane-per-ray walk adds two offsets, so the kernel turns
+    // instruction-bound at twice the time.  Kept as a selectable layout ("ray.layout" = 4), never chosen automatically.
+    const bool span_ok = a.max_length >= 1 && a.max_length <= 1024 && (int64_t)c->n_yaw * c->n_elev <= 512;
+    if (span_ok && c->opt_layout == 4) {
+        if (!c->have_cells_t) {
+            const size_t total = (size_t)c->nx * (size_t)c->ny * (size_t)c->nz;
+            if (c->d_cells_t.ensure(total) != hipSuccess || fs_launch_transpose(c->d_cells.p, c->d_cells_t.p, c->nx, c->ny, c->nz, c->stream) != hipSuccess)
+                return fail(c, FS_E_HIP, "could not stage the transposed grid image for the span walk");
+            c->have_cells_t = true;
+            a.grid = grid_dev(c);
+        }
+        a.bricked = 3;
+    }
     const bool planar = c->n_elev == 1 && p.elev[0] == 0.0;
     if (planar && a.max_length >= 1 && a.max_length <= 64 && c->opt_layout == 3) {
         a.bricked = 2;
@@ -533,7 +553,7 @@ void fs_ctx_destroy(fs_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_bricks.release();
+    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_bricks.release(); c->d_cells_t.release();
     c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
     c->d_kf_check.release(); c->d_kf_tri.release(); c->d_kf_off.release(); c->d_kf_flagged.release(); c->d_kf_cells.release();
@@ -822,7 +842,7 @@ int fs_max_arrival(fs_ctx *c, double *max_value, double *max_gt, double *min_gt)
     int rc = check_scoring_state(c, true, false);
     if (rc) return rc;
     FsRayArgs a{};
-    fill_ray_args(c, a);
+    if (const int rc_args = fill_ray_args(c, a)) return rc_args;
     // DEP/src/CostCalculator.cpp:140 visitor (260,260,0,255); :142-148 no clamping; start (0,0)
     a.obst_min = 260; a.obst_max = 260; a.trace_min = 0; a.trace_max = 255;
     a.clamp = 0;
@@ -911,7 +931,7 @@ int fs_score_arrival(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t
     const size_t per = (size_t)c->n_yaw * c->n_elev;
     if (ray_counts) FS_HIP(c, c->d_raycounts.ensure((size_t)n * per));
     FsRayArgs a{};
-    fill_ray_args(c, a);
+    if (const int rc_args = fill_ray_args(c, a)) return rc_args;
     a.n = n; a.goal = c->d_goal.p;
     a.frontier_size = frontier_size ? c->d_fsize.p : nullptr;
     a.blacklisted = blacklisted ? c->d_black.p : nullptr;
@@ -1070,7 +1090,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 3) { c->opt_layout = (int)value; return FS_OK; }
+    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 4) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);
@@ -1397,7 +1417,7 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     rc = ensure_candidate_scratch(c, n, false);
     if (rc) return rc;
     FsRayArgs ra{};
-    fill_ray_args(c, ra);
+    if (const int rc_args = fill_ray_args(c, ra)) return rc_args;
     ra.n = n; ra.goal = d_goal_xyz;
     ra.frontier_size = d_frontier_size; ra.blacklisted = d_blacklisted; ra.achievable_in = d_achievable_in;
     ra.ray_counts = nullptr;

@@ -130,7 +130,42 @@ __global__ void fs_retile_kernel(const uint8_t *__restrict__ cells, uint8_t *__r
     }
 }
 
+// dense row-major grid [z][y][x] -> its in-plane transpose [z][x][y] (the image y-major rays of the span walk read):
+// 32 x 32 tiles through LDS so that both the reads and the writes are coalesced
+__global__ void fs_transpose_kernel(const uint8_t *__restrict__ cells, uint8_t *__restrict__ cells_t, int nx, int ny, int nz)
+{
+    __shared__ uint8_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
+    const int tiles_x = (nx + 31) >> 5, tiles_y = (ny + 31) >> 5;
+    const long long n_tiles = (long long)tiles_x * tiles_y * nz;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int bx = (int)(t % tiles_x);
+        const long long r = t / tiles_x;
+        const int by = (int)(r % tiles_y), z = (int)(r / tiles_y);
+        const size_t slice = (size_t)z * (size_t)ny * (size_t)nx;
+        for (int j = ty; j < 32; j += 8) {
+            const int x = bx * 32 + tx, y = by * 32 + j;
+            tile[j][tx] = (x < nx && y < ny) ? cells[slice + (size_t)y * nx + x] : (uint8_t)255;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int x = bx * 32 + j, y = by * 32 + tx;
+            if (x < nx && y < ny) cells_t[slice + (size_t)x * ny + y] = tile[tx][j];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+hipError_t fs_launch_transpose(const uint8_t *d_cells, uint8_t *d_cells_t, int nx, int ny, int nz, hipStream_t s)
+{
+    const long long n_tiles = (long long)((nx + 31) >> 5) * ((ny + 31) >> 5) * nz;
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fs_transpose_kernel, dim3((unsigned)(n_tiles < 65536 * 8 ? n_tiles : 65536 * 8)), dim3(256), 0, s,
+                       d_cells, d_cells_t, nx, ny, nz);
+    return hipGetLastError();
+}
 
 hipError_t fs_launch_retile(const uint8_t *d_cells, uint8_t *d_bricks, int nx, int ny, int nz, hipStream_t s)
 {

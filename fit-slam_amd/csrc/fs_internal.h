@@ -20,6 +20,7 @@ struct FsGridDev {
     const uint8_t *bricks;     // [ceil(nz/2)][by][bx][2][8][8]
     int32_t bx, by;            // bricks per row / per column: ceil(nx/8), ceil(ny/8)
     unsigned long long *dbg;   // range-checked builds (FS_BOUNDS=1): where a walk that left the grid is recorded
+    const uint8_t *cells_t;    // [nz][nx][ny]: the in-plane transpose, read by y-major rays of the span walk
 };
 
 #define FS_BRICK_BYTES 128
@@ -29,6 +30,7 @@ __host__ __device__ inline size_t fs_brick_offset(uint32_t bx, uint32_t by, uint
     return ((size_t)b << 7) | ((z & 1u) << 6) | ((y & 7u) << 3) | (x & 7u);
 }
 hipError_t fs_launch_retile(const uint8_t *d_cells, uint8_t *d_bricks, int nx, int ny, int nz, hipStream_t s);
+hipError_t fs_launch_transpose(const uint8_t *d_cells, uint8_t *d_cells_t, int nx, int ny, int nz, hipStream_t s);
 
 struct FsRayArgs {
     FsGridDev grid;
@@ -40,7 +42,8 @@ struct FsRayArgs {
     uint32_t max_length;       // (unsigned)(max_camera_depth / resolution), CostCalculator.cpp:28
     int32_t obst_min, obst_max, trace_min, trace_max;
     int32_t clamp;             // CostCalculator.cpp:47-48 (1) or setMaxArrivalInformation (0)
-    int32_t bricked;           // 0: row-major image, 1: the 8x8x2-brick copy (long rays), 2: the fan's neighbourhood staged in LDS (planar fans)
+    int32_t bricked;           // 0: row-major image, 1: the 8x8x2-brick copy (long rays), 2: the fan's neighbourhood staged in LDS (planar fans),
+                               // 3: span walk (16 lanes = 16 consecutive steps of one ray, row-major image or its transpose by major axis)
     int32_t tile_stride;       // LDS tile of layout 2: (2 * max_length + 1) rows of tile_stride bytes (a multiple of 4)
     uint32_t tile_magic;       // ceil(2^32 / (tile_stride / 4)): row of a staged dword without an integer division
     double lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // folded clamp bounds: max(poly_min, origin), min(poly_max, origin + sizeInMeters)

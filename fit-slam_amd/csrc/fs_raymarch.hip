@@ -237,6 +237,20 @@ __device__ __forceinline__ void stage_tile(const FsRayArgs &a, const TileGeom &t
     }
 }
 
+// WalkSpan — a tag: the fan is walked by span_fan below, where SIXTEEN LANES TAKE SIXTEEN CONSECUTIVE STEPS OF ONE RAY
+// (four rays per wave instruction) instead of one lane walking one ray.  Why: with a lane per ray a 64-lane byte load
+// touches one cache line per live ray (~40 at L = 40) and the kernel runs at the L1's line rate;
+// sixteen consecutive cells of a ray lie in one or two lines when they are read from the image whose rows run along the
+// ray's major axis — the row-major image for x-major rays, its in-plane transpose (FsGridDev::cells_t) for y-major
+// ones.  The cell of step s needs no loop: bresenham2D's error term advances by |d_minor| per step and wraps at
+// |d_major| (Helpers.cpp:21-27), so after s steps a minor axis has moved floor((|d_major| / 2 + s |d_minor|) / |d_major|)
+// cells — evaluated with a multiply-high by a per-ray reciprocal that is exact for the step counts admitted here
+// (fs_capi.hip: max_length <= 1024).  First-obstacle semantics are a ballot: a cell counts if it is in the trace range
+// and no lower step of its ray hit the obstacle range.
+struct WalkSpan {};
+
+#define FS_SPAN_WORDS 8      // per-ray descriptor in LDS: base, off_a, off_b, off_c, |da| | |db| << 16, |dc| | end << 16, magic, flags
+
 // The start cell is the same for every ray of a fan: its worldToMap (three fp64 divisions) is done once per candidate;
 // a start point off the map fails every ray, like the reference's `||` of the two conversions (Helpers.cpp:40).
 template <typename Walk>
@@ -331,6 +345,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
     uint32_t sxm = 0, sym = 0, szm = 0;
     const bool start_ok = active && world_to_map(a.grid, sx, sy, sz, sxm, sym, szm);
     constexpr bool kTile = std::is_same<Walk, WalkTile>::value;
+    constexpr bool kSpan = std::is_same<Walk, WalkSpan>::value;
     TileGeom tg{nullptr, 0, 0, 0};
     if (kTile) {
         const int L = (int)a.max_length;
@@ -341,6 +356,106 @@ void fs_raymarch_kernel(const FsRayArgs a)
         if (start_ok && !black) stage_tile(a, tg, szm, lane);
         __syncthreads();                                    // the tile is written and read by the same wave; all waves pass here
     }
+    if constexpr (kSpan) {
+        // ---- phase 1: every lane prepares the descriptors of its rays (fp64 end points exactly as below)
+        uint32_t *desc = reinterpret_cast<uint32_t *>(fs_ray_lds + FS_RAY_WAVES * a.n_yaw) + (size_t)wave * (size_t)n_rays * FS_SPAN_WORDS;
+        if (active && !black) {
+            const uint32_t nx = (uint32_t)a.grid.nx, ny = (uint32_t)a.grid.ny;
+            for (int r = lane; r < n_rays; r += 64) {
+                double wx = sx + a.dir[3 * r];               // DEP/src/CostCalculator.cpp:42-43
+                double wy = sy + a.dir[3 * r + 1];
+                double wz = sz + a.dir[3 * r + 2];
+                if (a.clamp) {                                  // :47-48
+                    wx = std_max(a.lo_x, std_min(a.hi_x, wx));
+                    wy = std_max(a.lo_y, std_min(a.hi_y, wy));
+                    wz = std_max(a.lo_z, std_min(a.hi_z, wz));
+                }
+                uint32_t x1, y1, z1;
+                const bool ok = world_to_map(a.grid, wx, wy, wz, x1, y1, z1) && start_ok;
+                uint32_t d[FS_SPAN_WORDS] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                if (ok) {
+                    const int dx = (int)(x1 - sxm), dy = (int)(y1 - sym), dz = (int)(z1 - szm);
+                    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
+                    const bool xmaj = adx >= ady && adx >= adz, ymaj = !xmaj && ady >= adz;      // Helpers.cpp:56,77 with a third axis
+                    const uint32_t transposed = ymaj ? 1u : 0u;        // y-major rays read the image whose rows run along y
+                    const int stx = transposed ? (int)ny : 1, sty = transposed ? 1 : (int)nx, stz = (int)(nx * ny);
+                    const int ox_ = sign_ref(dx) * stx, oy_ = sign_ref(dy) * sty, oz_ = sign_ref(dz) * stz;
+                    uint32_t da, db, dc; int oa, ob, oc;
+                    if (xmaj) { da = adx; db = ady; dc = adz; oa = ox_; ob = oy_; oc = oz_; }
+                    else if (ymaj) { da = ady; db = adx; dc = adz; oa = oy_; ob = ox_; oc = oz_; }
+                    else { da = adz; db = adx; dc = ady; oa = oz_; ob = ox_; oc = oy_; }
+                    const uint32_t end = walk_visits(dx, dy, dz, da, (double)a.max_length);
+                    // ceil(2^32 / da) (exact in fp64 for da <= 2^11); da == 1: 2^31 with the numerator doubled (flag bit 2)
+                    uint32_t magic = 0u, unit = 0u;
+                    if (da == 1u) { magic = 0x80000000u; unit = 1u; }
+                    else if (da > 1u) magic = (uint32_t)ceil(4294967296.0 / (double)da);
+                    d[0] = szm * (uint32_t)stz + sym * (uint32_t)sty + sxm * (uint32_t)stx;
+                    d[1] = (uint32_t)oa; d[2] = (uint32_t)ob; d[3] = (uint32_t)oc;
+                    d[4] = da | (db << 16); d[5] = dc | (end << 16);
+                    d[6] = magic; d[7] = 1u | (transposed << 1) | (unit << 2);
+                } else {
+                    fail = true;
+                }
+                uint4 *dst = reinterpret_cast<uint4 *>(desc + (size_t)r * FS_SPAN_WORDS);
+                dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
+                dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
+            }
+        }
+        __syncthreads();                                    // descriptors are written and read by the same wave; all waves pass here
+        // ---- phase 2: four rays per wave instruction, sixteen consecutive steps each
+        if (active && !black) {
+            const int omin = a.obst_min > 0 ? a.obst_min : 0, omax = a.obst_max < 255 ? a.obst_max : 255;
+            const int tmin = a.trace_min > 0 ? a.trace_min : 0, tmax = a.trace_max < 255 ? a.trace_max : 255;
+            const bool o_any = omax >= omin, t_any = tmax >= tmin;
+            const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
+            const int row = lane >> 4, sl = lane & 15;
+            const uint32_t below = (1u << sl) - 1u;                       // lower steps of my ray within a group
+            for (int q = 0; q < n_rays; q += 4) {
+                const int r = q + row;
+                uint4 d0 = make_uint4(0u, 0u, 0u, 0u), d1 = make_uint4(0u, 0u, 0u, 0u);
+                if (r < n_rays) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(desc + (size_t)r * FS_SPAN_WORDS);
+                    d0 = src[0]; d1 = src[1];
+                }
+                const uint32_t da = d1.x & 0xffffu, db = d1.x >> 16, dc = d1.y & 0xffffu, end = d1.y >> 16;
+                const uint32_t sh = (d1.w >> 2) & 1u, e0 = da >> 1;
+                const uint8_t *img = (d1.w & 2u) ? a.grid.cells_t : a.grid.cells;
+                bool alive = (d1.w & 1u) != 0u;
+                int count = 0;
+                for (uint32_t g0 = 0; ; g0 += 16) {
+                    const uint32_t s = g0 + (uint32_t)sl;
+                    const bool in = alive && s <= end;
+                    if (!__any(in)) break;
+                    // cells moved along the two minor axes after s steps (see the comment at WalkSpan)
+                    const uint32_t nb = __umulhi((e0 + s * db) << sh, d1.z), nc = __umulhi((e0 + s * dc) << sh, d1.z);
+                    const uint32_t off = d0.x + s * d0.y + nb * d0.z + nc * d0.w;
+                    int c = -1;
+                    if (in) {
+#ifdef FS_RAY_BOUNDS
+                        if (off >= (uint32_t)a.grid.nx * (uint32_t)a.grid.ny * (uint32_t)a.grid.nz) { atomicMax(a.grid.dbg, 3ull); }
+                        else
+#endif
+                        c = (int)img[off];
+                    }
+                    const bool hit = o_any && (uint32_t)(c - omin) <= orange;
+                    const bool tr = t_any && (uint32_t)(c - tmin) <= trange;
+                    // my ray's 16 steps of this group within the wave-wide masks
+                    const unsigned long long hm = __ballot(hit);
+                    const uint32_t hseg = ((lane & 32) ? (uint32_t)(hm >> 32) : (uint32_t)hm) >> (lane & 16) & 0xffffu;
+                    // Helpers.hpp:64-71: the traced test comes before hit_obstacle is set, so the obstacle cell itself still counts
+                    const bool counted = tr && (hseg & below) == 0u;
+                    const unsigned long long cm = __ballot(counted);
+                    const uint32_t cseg = ((lane & 32) ? (uint32_t)(cm >> 32) : (uint32_t)cm) >> (lane & 16) & 0xffffu;
+                    count += __popc(cseg);
+                    alive = alive && hseg == 0u;                           // nothing is pushed after the first obstacle
+                }
+                if (sl == 0 && r < n_rays) {
+                    if (count) atomicAdd(&ysum[r % a.n_yaw], count);
+                    if (a.ray_counts) a.ray_counts[(size_t)c * n_rays + r] = count;
+                }
+            }
+        }
+    } else
     if (active && !black) {
         for (int r = lane; r < n_rays; r += 64) {
             const int i = r % a.n_yaw;
@@ -481,7 +596,15 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
     int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
     if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
-    if (a.bricked == 2) {
+    if (a.bricked == 3) {
+        const size_t lds_s = lds + (size_t)FS_RAY_WAVES * (size_t)a.n_yaw * (size_t)a.n_elev * FS_SPAN_WORDS * sizeof(uint32_t);
+        auto kernel = fs_raymarch_kernel<WalkSpan>;
+        if (lds_s > 48 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds_s, s, a);
+    } else if (a.bricked == 2) {
         const size_t tile = (size_t)(2 * a.max_length + 1) * (size_t)a.tile_stride;
         const size_t lds_t = lds + FS_RAY_WAVES * tile;
         auto kernel = fs_raymarch_kernel<WalkTile>;

@@ -420,8 +420,9 @@ def test_information_for_pose_hbm_table_pass(fs, oracle, scorer):
 
 
 def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
-    """The row-major walk and the walk over the 8x8x2-brick copy visit the same cells: bit-exact against the oracle and
-    against each other, for short and long rays, odd grid sizes (partial bricks) and arbitrary segments."""
+    """The row-major walk, the walk over the 8x8x2-brick copy, the LDS-staged fan and the span walk (16 lanes = 16 steps
+    of one ray, row-major image or its transpose) visit the same cells: bit-exact against the oracle and against each
+    other, for short and long rays, odd grid sizes (partial bricks) and arbitrary segments."""
     rng = np.random.default_rng(77)
     try:
         for name, depth_cells in (("C1_2D", 40), ("C1", 40), ("C2", 160)):
@@ -431,7 +432,7 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
             _setup_scorer(scorer, w)
             mx_o = oracle.max_arrival_information(G, P)
             want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], n_threads=8)
-            for layout in (1, 2, 3, 0):                        # 3: LDS-staged fan where the fan is planar, else as 0
+            for layout in (1, 2, 3, 4, 0):                     # 3: LDS-staged fan where the fan is planar, else as 0; 4: span walk
                 scorer.set_option("ray.layout", layout)
                 assert scorer.max_arrival() == mx_o
                 _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
@@ -487,7 +488,7 @@ def test_lds_staged_fan_walk_equals_the_other_walks(fs, oracle, scorer):
                 mx_o = oracle.max_arrival_information(G, P)
                 want = oracle.arrival_information(G, P, goals, fsize, black, min_gt=mx_o["min_gt"], faithful=True)
                 res = {}
-                for layout in (3, 1):
+                for layout in (3, 4, 1):
                     scorer.set_option("ray.layout", layout)
                     assert scorer.max_arrival() == mx_o
                     res[layout] = scorer.score_arrival(goals, fsize, black, want_ray_counts=True)
