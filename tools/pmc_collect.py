@@ -237,7 +237,7 @@ def main():
             if u >= 0.75:
                 summary["bound"] = "valu-issue"
             elif w_any + (w_inst or 0.0) >= 0.5:
-                summary["bound"] = "latency (waves parked on LDS-atomic / barrier / load waits; 4 waves per SIMD)"
+                summary["bound"] = "latency"      # waves parked on LDS-atomic / barrier / load waits at 4 waves per SIMD
             else:
                 summary["bound"] = "mixed"
             summary["bound_evidence"] = (
