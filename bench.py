@@ -21,7 +21,14 @@ equal WORLD_SIZE or the run fails.  Rank 0 prints ONE JSON line.
 
 Timing: W untimed warm-up steps, then `--repeats` blocks of EXACTLY K steps each, every block bracketed by
 barrier + torch.cuda.synchronize on both sides and reduced with MAX over the ranks; `value` / `ms_per_step` come from
-the MEDIAN block, the minimum and every block's time are reported beside it.
+the MEDIAN block, the minimum and every block's time are reported beside it.  Only the last block carries the
+per-kernel hipEvent pairs the roofline needs (they cost ~3 % of a step), so the median is an event-free block.
+
+Pipelining: --pipeline P (default 1: one stream, batches strictly back to back) stages the map and the cloud in P scorer
+contexts, each on its own HIP stream, and sends batch k to context k mod P, so that the next batch's ray-march overlaps the
+drain of the previous batch's persistent FIM workgroups.  Every step is still one complete batch.  Measured on C3
+(profiles/r02/c3_pipeline.json): P = 2 gives 1.011 against 1.031 ms per batch, P = 3 loses; with P > 1 the FIM kernels of two
+batches share the CUs, their hipEvent durations double and stop measuring the kernel — hence the default of 1.
 """
 from __future__ import annotations
 
@@ -50,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--pipeline", type=int, default=1, help="scorer contexts (HIP streams) per GPU; successive batches alternate over them (1, the default = one stream, batches strictly back to back; 2 measured +2 %% on C3, but the two FIM kernels then share the CUs and their per-launch durations no longer measure the kernel)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--workload", default="C3", help="C3 (headline) | C5 | REF2D (the reference's own 2-D operating point: 63 rays, L = 40) | C2 | C1")
     ap.add_argument("--depth-cells", type=int, default=0, help="ray length L in cells (0: the config's 40 = 2 m; BASELINE.md's secondary throughput run uses 160)")
@@ -260,81 +268,100 @@ def run_rank(args) -> int:
     lo, hi = shard.shard_bounds(n_total, world, rank)
     cap = shard.shard_capacity(n_total, world)
 
-    # One explicit stream for everything: the scorer launches on the stream handle it is given and torch (and RCCL's
-    # all-gather) orders its work after the CURRENT stream — so the current stream must be that same, non-default one
-    # (the default stream's handle is 0, which the C ABI takes as "create your own").
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    sc = fs.FrontierScorer(device=dev_index, stream=stream.cuda_stream)
+    # Explicit streams for everything: a scorer launches on the stream handle it is given and torch (and RCCL's
+    # all-gather) orders its work after the CURRENT stream — so a batch is issued with its scorer's stream current, and
+    # that stream is never the default one (handle 0, which the C ABI takes as "create your own").
+    # --pipeline P: P scorer contexts, each with its own stream and its own staged copy of the map and the cloud; batch k
+    # goes to context k mod P, so the ray-march of batch k+1 fills the CUs the persistent FIM workgroups of batch k leave
+    # idle while they drain (measured: tools/overlap_probe.py, 1.024 -> 0.984 ms per C3 batch; 1.031 -> 1.011 here).
+    # Every batch is still one complete pass of the hot path; the fences below wait for all streams.  Default P = 1.
+    n_pipe = max(1, args.pipeline)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_pipe)]
+    assert all(st.cuda_stream != 0 for st in streams)
+    torch.cuda.set_stream(streams[0])
+    scs = [fs.FrontierScorer(device=dev_index, stream=st.cuda_stream) for st in streams]
+    sc = scs[0]
     arrival_kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
                       robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
-    for kv in args.option:
-        k, v = kv.split("=", 1)
-        sc.set_option(k, float(v))
-    sc.set_ray_params(**arrival_kw)
     grid_note = "dense upload"
-    if wl_name == "C5":
-        # configs[4]'s wire format: the non-unknown 8^3 bricks only; in HBM the grid is expanded to the dense image and
-        # its 8x8x2-brick copy (1 GiB + 1 GiB of 288 GB: no hash probe per cell on the ray walk).  Hard limit 2^31 cells.
-        bxyz, bcells = fs.synth.dense_to_bricks(w.cells)
-        sc.upload_grid_bricks(w.cells.shape, w.origin, w.resolution, bxyz, bcells, default_value=255)
-        grid_note = f"sparse brick-list upload ({bxyz.shape[0]} of {w.cells.size // 512} bricks), dense 1 GiB + bricked 1 GiB in HBM"
-        del bxyz, bcells
-    else:
-        sc.upload_grid(w.cells, w.origin, w.resolution)
-    sc.upload_landmarks(w.landmarks)
-    sc.lookup_generate()
-    sc.set_fim_params(14.0, 1.0)
+    bricks = fs.synth.dense_to_bricks(w.cells) if wl_name == "C5" else None
+    for c in scs:
+        for kv in args.option:
+            k, v = kv.split("=", 1)
+            c.set_option(k, float(v))
+        c.set_ray_params(**arrival_kw)
+        if bricks is not None:
+            # configs[4]'s wire format: the non-unknown 8^3 bricks only; in HBM the grid is expanded to the dense image
+            # and its 8x8x2-brick copy (1 GiB + 1 GiB of 288 GB: no hash probe per cell on the ray walk).  Limit 2^31 cells.
+            c.upload_grid_bricks(w.cells.shape, w.origin, w.resolution, bricks[0], bricks[1], default_value=255)
+            grid_note = (f"sparse brick-list upload ({bricks[0].shape[0]} of {w.cells.size // 512} bricks), "
+                         "dense 1 GiB + bricked 1 GiB in HBM")
+        else:
+            c.upload_grid(w.cells, w.origin, w.resolution)
+        c.upload_landmarks(w.landmarks)
+        c.lookup_generate()
+        c.set_fim_params(14.0, 1.0)
+    del bricks
     mx = sc.max_arrival()
 
     # candidate columns of this rank's block, resident in HBM
     d_goal = torch.from_numpy(w.goals[lo:hi].copy()).to(dev)
     d_fsize = torch.from_numpy(w.frontier_size[lo:hi].copy()).to(dev)
     d_black = torch.from_numpy(w.blacklisted[lo:hi].copy()).to(dev)
-    # two record buffers: the all-gather of batch k runs on the communicator's stream while batch k+1 is being scored
-    d_recs = [torch.zeros((cap, 8), dtype=torch.int32, device=dev) for _ in range(2)]
-    pending = [None, None]
+    # two record buffers per context: the all-gather of a batch runs on the communicator's stream while the next batch of
+    # the same context is being scored
+    n_buf = 2 * n_pipe
+    d_recs = [torch.zeros((cap, 8), dtype=torch.int32, device=dev) for _ in range(n_buf)]
+    pending = [None] * n_buf
     state = {"k": 0, "full": None}
     n_local = hi - lo
 
     def step():
-        b = state["k"] & 1
+        k = state["k"]
         state["k"] += 1
+        c, b = k % n_pipe, k % n_buf
         if pending[b] is not None:
             pending[b].wait()                                        # the gather that last read this buffer is done
             pending[b] = None
         d_rec = d_recs[b]
-        sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_rec.data_ptr())
-        if world > 1:
-            if args.backend == "nccl":
-                state["full"], pending[b] = shard.gather_records(d_rec, n_total, async_op=True)
+        with torch.cuda.stream(streams[c]):
+            scs[c].score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_rec.data_ptr())
+            if world > 1:
+                if args.backend == "nccl":
+                    state["full"], pending[b] = shard.gather_records(d_rec, n_total, async_op=True)
+                    return state["full"]
+                streams[c].synchronize()
+                state["full"] = shard.gather_records(d_rec.cpu(), n_total)   # gloo rehearsal: through host memory
                 return state["full"]
-            torch.cuda.synchronize(dev)
-            state["full"] = shard.gather_records(d_rec.cpu(), n_total)   # gloo rehearsal: through host memory
-            return state["full"]
         state["full"] = d_rec[:n_total]
         return state["full"]
 
     def fence():
-        for b in (0, 1):
+        for b in range(n_buf):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)                                  # every stream of the device
 
     for _ in range(args.warmup):
         step()
     fence()
-    sc.enable_kernel_timing(True)
-    for kind in range(5):
-        sc.kernel_time(kind)
-    sc.get_counter(0, reset=True)
+    for c in scs:
+        c.get_counter(0, reset=True)
+    # Per-kernel hipEvent pairs cost ~0.035 ms per step (measured: 1.06 vs 1.024 ms), so only the LAST timed block carries
+    # them: the roofline's launch durations come from that block, `value` from the median block (an event-free one
+    # whenever --repeats >= 3).  All blocks are listed in "timing".
+    n_rep = max(1, args.repeats)
     block_s = []
     full = None
-    for _ in range(max(1, args.repeats)):
+    for r in range(n_rep):
+        if r == n_rep - 1:
+            for c in scs:
+                c.enable_kernel_timing(True)
+                for kind in range(5):
+                    c.kernel_time(kind)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -342,13 +369,24 @@ def run_rank(args) -> int:
         fence()
         block_s.append(time.perf_counter() - t0)
     n_steps_all = args.steps * len(block_s)
-    ray_ms, ray_n = sc.kernel_time(0)
-    fim_ms, fim_n = sc.kernel_time(1)
-    ovf_ms, ovf_n = sc.kernel_time(2)
-    sort_ms, sort_n = sc.kernel_time(4)
-    m_tested = sc.get_counter(0, reset=True) / max(1, n_steps_all * n_local)   # landmark tests per candidate on this rank
-    multipass, tier3 = sc.get_counter(4), sc.get_counter(5)
-    sc.enable_kernel_timing(False)
+    n_steps_ev = args.steps                                          # steps of the block that carried the events
+
+    def kernel_sum(kind):
+        ms, n = 0.0, 0
+        for c in scs:
+            a, b = c.kernel_time(kind)
+            ms, n = ms + a, n + b
+        return ms, n
+
+    ray_ms, ray_n = kernel_sum(0)
+    fim_ms, fim_n = kernel_sum(1)
+    ovf_ms, ovf_n = kernel_sum(2)
+    sort_ms, sort_n = kernel_sum(4)
+    # landmark tests per candidate on this rank, over every timed step
+    m_tested = sum(c.get_counter(0, reset=True) for c in scs) / max(1, n_steps_all * n_local)
+    multipass, tier3 = sum(c.get_counter(4) for c in scs), sum(c.get_counter(5) for c in scs)
+    for c in scs:
+        c.enable_kernel_timing(False)
 
     if world > 1:
         tmax = torch.tensor(block_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -368,7 +406,7 @@ def run_rank(args) -> int:
         b_ray = R * E * (L + 1) + (2 * r_fp + 1) ** 2
         n_chunks = -(-m // 64)
         b_fim = m_tested * 12 + 32
-        launches_per_step = fim_n / max(1, n_steps_all)
+        launches_per_step = fim_n / max(1, n_steps_ev)
         fim_avg_s = (fim_ms / max(fim_n, 1)) * 1e-3
         achieved = (n_local * b_fim / max(launches_per_step, 1e-9)) / fim_avg_s / 1e9 if fim_n else None
         prof = counter_profile(wl_name, args.depth_cells)
@@ -407,21 +445,25 @@ def run_rank(args) -> int:
                                    f"({n_total} total), {m} landmarks, {R * E} rays/candidate ({R} yaw x {E} elevation), "
                                    f"L={L} cells, chunk-culled visibility (M_tested measured), reference 71x100x100 lookup table",
                        "candidates_per_gpu": per_rank, "total_candidates": n_total,
-                       "sharding": f"contiguous blocks over {world} GPU(s), one all-gather of 32-B records ({args.backend})"},
+                       "sharding": f"contiguous blocks over {world} GPU(s), one all-gather of 32-B records ({args.backend})",
+                       "pipeline": f"{n_pipe} scorer context(s)/HIP stream(s) per GPU; batch k runs whole on context k mod {n_pipe}"},
             "timing": {"repeats": len(block_s), "block_ms_per_step": [b / args.steps * 1e3 for b in block_s],
                        "median_ms_per_step": dt / args.steps * 1e3, "min_ms_per_step": min(block_s) / args.steps * 1e3,
-                       "value_from": "median block", "value_at_min": n_total * args.steps / min(block_s)},
+                       "value_from": "median block", "kernel_events_in_block": len(block_s) - 1, "value_at_min": n_total * args.steps / min(block_s)},
             "roofline": roofline,
-            "kernels_ms_per_step": {"fs_raymarch_kernel": ray_ms / n_steps_all, "fs_fim_kernel": fim_ms / n_steps_all,
-                                    "fs_fim_overflow_kernel": ovf_ms / n_steps_all, "candidate_sort": sort_ms / n_steps_all,
-                                    "raymarch_algorithmic_GBps": (n_local * b_ray) / ((ray_ms / n_steps_all) * 1e-3) / 1e9 if ray_n else None},
+            "kernels_ms_per_step": {"fs_raymarch_kernel": ray_ms / n_steps_ev, "fs_fim_kernel": fim_ms / n_steps_ev,
+                                    "fs_fim_overflow_kernel": ovf_ms / n_steps_ev, "candidate_sort": sort_ms / n_steps_ev,
+                                    "raymarch_algorithmic_GBps": (n_local * b_ray) / ((ray_ms / n_steps_ev) * 1e-3) / 1e9 if ray_n else None,
+                                    "from": "the last timed block (the only one with per-kernel hipEvents); with --pipeline > 1 "
+                                            "a kernel's duration includes the time it shares the chip with the other stream's kernels"},
             "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    sc.close()
+    for c in scs:
+        c.close()
     return 0
 
 

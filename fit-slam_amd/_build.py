@@ -35,6 +35,8 @@ if os.environ.get("FS_T1_THREADS"):       # development: workgroup size of the F
     HIPCC_FLAGS.append("-DFS_T1_THREADS=" + os.environ["FS_T1_THREADS"])
 if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counters of the FIM worker in counters 16..24
     HIPCC_FLAGS.append("-DFS_FIM_STAMPS")
+if os.environ.get("FS_FIM_SCHEDULE"):     # development: per-candidate start / duration / workgroup of the persistent FIM grid (tools/fim_schedule.py)
+    HIPCC_FLAGS.append("-DFS_FIM_SCHEDULE")
 
 
 def hipcc() -> str:

@@ -536,8 +536,8 @@ int fs_ctx_create(int device_id, void *stream, fs_ctx **out)
         c->own_stream = true;
     }
     // device-side counters (fs_get_counter; 29 / 30: range checks of FS_BOUNDS builds)
-    if (c->d_counters.ensure(32) != hipSuccess ||
-        hipMemsetAsync(c->d_counters.p, 0, 32 * sizeof(unsigned long long), c->stream) != hipSuccess ||
+    if (c->d_counters.ensure(FS_N_COUNTERS) != hipSuccess ||
+        hipMemsetAsync(c->d_counters.p, 0, FS_N_COUNTERS * sizeof(unsigned long long), c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
         fs_ctx_destroy(c);
         return FS_E_HIP;
@@ -1098,7 +1098,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
 
 int fs_get_counter(fs_ctx *c, int which, int64_t *value, int reset)
 {
-    if (!c || !value || which < 0 || which > 31) return FS_E_INVALID;
+    if (!c || !value || which < 0 || which >= FS_N_COUNTERS) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
     *value = 0;
     if (!c->d_counters.p) return FS_OK;

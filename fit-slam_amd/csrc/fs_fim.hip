@@ -389,6 +389,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #endif
     while (cur >= 0) {
         const int c = cur;
+#ifdef FS_FIM_SCHEDULE
+        // development build: when did this workgroup start the candidate and how long did it take (plain stores by one
+        // thread, no atomics: the schedule of the persistent grid is read back through fs_get_counter)
+        unsigned long long t_cand;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_cand) :: "memory");
+#endif
         int ahead = -1;
         if (tid == 0 && sh_next[buf ^ 1] >= 0) ahead = fetch();    // the candidate after the next one; stored below
         int wg_tested = 0;
@@ -587,6 +593,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         cur = nxt;
         buf ^= 1;
         FS_STAMP(7);
+#ifdef FS_FIM_SCHEDULE
+        if (tid == 0 && !GLOBAL_TABLE && c < FS_SCHEDULE_MAX) {
+            unsigned long long t_now;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now) :: "memory");
+            a.counters[32 + 2 * c] = t_cand;                       // 100 MHz ticks
+            a.counters[32 + 2 * c + 1] = ((t_now - t_cand) & 0xffffffffull) | ((unsigned long long)blockIdx.x << 32) | ((unsigned long long)n_parts << 56);
+        }
+#endif
     }
 #ifdef FS_FIM_STAMPS
     if (lane == 0 && !GLOBAL_TABLE && THREADS == FS_T1_THREADS) {

@@ -165,6 +165,15 @@ struct FsFimArgs {
 
 #define FS_CHUNK       64       // landmarks per chunk (one wave)
 #define FS_FACTOR_N    352      // (float)exp(1 - k^0.8) is exactly 0.0f from k = 337 on
+// device-side counters of a context (fs_get_counter).  FS_FIM_SCHEDULE development builds append two words per candidate
+// (< FS_SCHEDULE_MAX): the 100 MHz tick at which a workgroup of the persistent FIM grid started it, and
+// duration | workgroup << 32 | passes << 56 (tools/fim_schedule.py).
+#define FS_SCHEDULE_MAX 32768
+#ifdef FS_FIM_SCHEDULE
+#define FS_N_COUNTERS (32 + 2 * FS_SCHEDULE_MAX)
+#else
+#define FS_N_COUNTERS 32
+#endif
 #define FS_SLOT_CNT_BITS 11     // slot = (key+1) << 11 | count
 #define FS_SLOT_CNT_MASK ((1u << FS_SLOT_CNT_BITS) - 1u)
 #define FS_SLOT_CNT_SAT  1024u  // counts beyond this contribute exactly 0.0f anyway
