@@ -68,6 +68,8 @@ struct fs_ctx {
     bool have_grid = false;
     DevBuf<uint8_t> d_cells, d_bricks, d_cells_t;   // dense row-major image, its 8x8x2-brick copy and its in-plane transpose (FsGridDev)
     bool have_cells_t = false;                      // d_cells_t matches d_cells (built lazily: only "ray.layout" = 4 reads it)
+    DevBuf<uint8_t> d_cells_z;                      // [ny][nx][nz], the column image (built lazily: "ray.layout" = 5)
+    bool have_cells_z = false;
     int32_t nx = 0, ny = 0, nz = 0;
     double origin[3] = {0, 0, 0};
     double res = 0.0;
@@ -137,7 +139,11 @@ struct fs_ctx {
     DevBuf<fs_frontier_cluster> d_fc_clusters;
     DevBuf<long long> d_fc_sums;
     bool opt_sort = true;
-    int opt_layout = 0;            // 0 auto, 1 row-major walk (a lane per ray), 2 bricked walk, 3 LDS-staged fan (planar fans; else auto), 4 span walk
+    bool opt_sort_reverse = false; // development: blocks in reverse Morton order (order-sensitivity measurements)
+    bool opt_costmap = true;       // the spatial sort puts the blocks that were expensive in the previous call first ("sort.costmap")
+    const uint32_t *sort_keys = nullptr;   // this call's sort keys / the cost map inside sort_scratch (nullptr: list not sorted)
+    uint32_t *sort_costmap = nullptr;
+    int opt_layout = 0;            // 0 auto, 1 row-major walk (a lane per ray), 2 bricked walk, 3 LDS-staged fan (planar fans; else auto), 4 span walk, 5 column walk
 
     // timing
     bool timing = false;
@@ -374,7 +380,7 @@ int use_bricks(const fs_ctx *c, double max_length_cells)
 FsGridDev grid_dev(const fs_ctx *c)
 {
     return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res,
-                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3, c->d_counters.p + 29, c->d_cells_t.p};
+                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3, c->d_counters.p + 29, c->d_cells_t.p, c->d_cells_z.p};
 }
 
 // every upload path ends here: the ray kernels read the bricked copy
@@ -384,6 +390,7 @@ int retile_grid(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz)
     FS_HIP(c, c->d_bricks.ensure(bytes));
     FS_HIP(c, fs_launch_retile(c->d_cells.p, c->d_bricks.p, nx, ny, nz, c->stream));
     c->have_cells_t = false;                         // the transposed image (span walk only) is rebuilt on demand
+    c->have_cells_z = false;
     return FS_OK;
 }
 
@@ -426,6 +433,20 @@ int fill_ray_args(fs_ctx *c, FsRayArgs &a)
             a.grid = grid_dev(c);
         }
         a.bricked = 3;
+    }
+    // Column walk (fs_raymarch.hip, WalkColumn): the row-major walk on the z-fastest image with the elevation rings of a yaw
+    // in neighbouring lanes — 16 instead of ~38 lines per wave load.  Measured on C3 (profiles/r02/c3_column_walk.json):
+    // 0.286 against 0.226 ms: a column line is left after one step, the L1 misses more and the L2 -> L1 fill becomes the
+    // limit.  Selectable ("ray.layout" = 5), never chosen automatically.
+    if (c->opt_layout == 5 && c->nz > 1) {
+        if (!c->have_cells_z) {
+            const size_t total = (size_t)c->nx * (size_t)c->ny * (size_t)c->nz;
+            if (c->d_cells_z.ensure(total) != hipSuccess || fs_launch_columns(c->d_cells.p, c->d_cells_z.p, c->nx, c->ny, c->nz, c->stream) != hipSuccess)
+                return fail(c, FS_E_HIP, "could not stage the column image of the grid");
+            c->have_cells_z = true;
+            a.grid = grid_dev(c);
+        }
+        a.bricked = 4;
     }
     const bool planar = c->n_elev == 1 && p.elev[0] == 0.0;
     if (planar && a.max_length >= 1 && a.max_length <= 64 && c->opt_layout == 3) {
@@ -553,7 +574,7 @@ void fs_ctx_destroy(fs_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_bricks.release(); c->d_cells_t.release();
+    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_bricks.release(); c->d_cells_t.release(); c->d_cells_z.release();
     c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
     c->d_kf_check.release(); c->d_kf_tri.release(); c->d_kf_off.release(); c->d_kf_flagged.release(); c->d_kf_cells.release();
@@ -884,10 +905,12 @@ int fs_max_arrival(fs_ctx *c, double *max_value, double *max_gt, double *min_gt)
 static int maybe_sort(fs_ctx *c, FsRayArgs &a)
 {
     a.perm = nullptr;
+    c->sort_keys = nullptr; c->sort_costmap = nullptr;
     if (!c->opt_sort || a.n < 2048) return FS_OK;
     FS_HIP(c, c->d_perm.ensure(a.n));
     ScopedTimer t(c, 4);
-    FS_HIP(c, fs_launch_sort_candidates(a.n, a.goal, a.grid, c->d_perm.p, &c->sort_scratch, &c->sort_scratch_bytes, c->stream));
+    FS_HIP(c, fs_launch_sort_candidates(a.n, a.goal, a.grid, c->d_perm.p, &c->sort_scratch, &c->sort_scratch_bytes,
+                                        c->d_counters.p + 10, &c->sort_keys, &c->sort_costmap, c->opt_costmap ? 1 : 0, c->opt_sort_reverse ? 1 : 0, c->stream));
     a.perm = c->d_perm.p;
     return FS_OK;
 }
@@ -1090,7 +1113,9 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 4) { c->opt_layout = (int)value; return FS_OK; }
+    if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 5) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);
@@ -1431,6 +1456,7 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     fill_fim_args(c, fa);
     fa.n = n; fa.Rt = c->d_Rt.p;
     fa.status = c->d_status.p;
+    if (ra.perm && c->opt_costmap) { fa.costmap = c->sort_costmap; fa.cand_key = c->sort_keys; }   // heavy blocks first next time
     fa.fim21 = nullptr;
     bind_fim_outputs(c, fa);
     {

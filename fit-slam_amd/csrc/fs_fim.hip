@@ -582,6 +582,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (tid == 0) {
             a.overflow[c] = failed ? fail_code : 0u;                  // the HBM tier re-scores flagged candidates
             if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);   // landmarks tested (M_tested), summed by the finish kernel
+            // what this candidate cost, filed under its block of the map for the order of the next call (fs_sort.hip)
+            if (!GLOBAL_TABLE && a.costmap) atomicMax(&a.costmap[a.cand_key[c] & (FS_COST_BINS - 1)], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);
             if (!GLOBAL_TABLE && n_parts > 1 && !failed) atomicAdd(&a.counters[1], 1ull);   // scored in several passes
             if (failed && !GLOBAL_TABLE) {
                 const unsigned long long slot = atomicAdd(&a.counters[2], 1ull);
@@ -641,12 +643,13 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
         unsigned long long tsum = (c < a.n) ? (unsigned long long)a.tested[c] : 0ull;
         if (c < a.n) a.tested[c] = 0u;
         for (int d = 32; d >= 1; d >>= 1) tsum += __shfl_xor(tsum, d);
-        if ((threadIdx.x & 63) == 0 && tsum) atomicAdd(&a.counters[0], tsum);
+        if ((threadIdx.x & 63) == 0 && tsum) { atomicAdd(&a.counters[0], tsum); atomicAdd(&a.counters[10], tsum); }
     }
     if (c == 0) {                                            // per-call tier counters -> running totals
         a.counters[4] += a.counters[1];
         a.counters[5] += a.counters[2];
         a.counters[6] += a.counters[3];
+        atomicAdd(&a.counters[11], (unsigned long long)a.n);
         a.counters[1] = 0ull; a.counters[2] = 0ull; a.counters[3] = 0ull; a.counters[7] = 0ull; a.counters[8] = 0ull; a.counters[9] = 0ull;
     }
     if (c >= a.n) return;

@@ -156,7 +156,41 @@ __global__ void fs_transpose_kernel(const uint8_t *__restrict__ cells, uint8_t *
     }
 }
 
+// dense row-major grid [z][y][x] -> the column image [y][x][z] (z runs fastest: the cells a fan's elevation rings visit above
+// one another share a cache line): per y, the (z, x) plane is transposed in 32 x 32 tiles through LDS
+__global__ void fs_columns_kernel(const uint8_t *__restrict__ cells, uint8_t *__restrict__ cells_z, int nx, int ny, int nz)
+{
+    __shared__ uint8_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
+    const int tiles_x = (nx + 31) >> 5, tiles_z = (nz + 31) >> 5;
+    const long long n_tiles = (long long)tiles_x * tiles_z * ny;
+    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int bx = (int)(t % tiles_x);
+        const long long r = t / tiles_x;
+        const int bz = (int)(r % tiles_z), y = (int)(r / tiles_z);
+        for (int j = ty; j < 32; j += 8) {
+            const int x = bx * 32 + tx, z = bz * 32 + j;
+            tile[j][tx] = (x < nx && z < nz) ? cells[((size_t)z * ny + y) * (size_t)nx + x] : (uint8_t)255;
+        }
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const int x = bx * 32 + j, z = bz * 32 + tx;
+            if (x < nx && z < nz) cells_z[((size_t)y * nx + x) * (size_t)nz + z] = tile[tx][j];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+hipError_t fs_launch_columns(const uint8_t *d_cells, uint8_t *d_cells_z, int nx, int ny, int nz, hipStream_t s)
+{
+    const long long n_tiles = (long long)((nx + 31) >> 5) * ((nz + 31) >> 5) * ny;
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fs_columns_kernel, dim3((unsigned)(n_tiles < 65536 * 8 ? n_tiles : 65536 * 8)), dim3(256), 0, s,
+                       d_cells, d_cells_z, nx, ny, nz);
+    return hipGetLastError();
+}
 
 hipError_t fs_launch_transpose(const uint8_t *d_cells, uint8_t *d_cells_t, int nx, int ny, int nz, hipStream_t s)
 {

@@ -21,6 +21,7 @@ struct FsGridDev {
     int32_t bx, by;            // bricks per row / per column: ceil(nx/8), ceil(ny/8)
     unsigned long long *dbg;   // range-checked builds (FS_BOUNDS=1): where a walk that left the grid is recorded
     const uint8_t *cells_t;    // [nz][nx][ny]: the in-plane transpose, read by y-major rays of the span walk
+    const uint8_t *cells_z;    // [ny][nx][nz]: z runs fastest — one cache line holds 128 cells of a COLUMN, read by the column walk
 };
 
 #define FS_BRICK_BYTES 128
@@ -31,6 +32,7 @@ __host__ __device__ inline size_t fs_brick_offset(uint32_t bx, uint32_t by, uint
 }
 hipError_t fs_launch_retile(const uint8_t *d_cells, uint8_t *d_bricks, int nx, int ny, int nz, hipStream_t s);
 hipError_t fs_launch_transpose(const uint8_t *d_cells, uint8_t *d_cells_t, int nx, int ny, int nz, hipStream_t s);
+hipError_t fs_launch_columns(const uint8_t *d_cells, uint8_t *d_cells_z, int nx, int ny, int nz, hipStream_t s);
 
 struct FsRayArgs {
     FsGridDev grid;
@@ -43,7 +45,8 @@ struct FsRayArgs {
     int32_t obst_min, obst_max, trace_min, trace_max;
     int32_t clamp;             // CostCalculator.cpp:47-48 (1) or setMaxArrivalInformation (0)
     int32_t bricked;           // 0: row-major image, 1: the 8x8x2-brick copy (long rays), 2: the fan's neighbourhood staged in LDS (planar fans),
-                               // 3: span walk (16 lanes = 16 consecutive steps of one ray, row-major image or its transpose by major axis)
+                               // 3: span walk (16 lanes = 16 consecutive steps of one ray, row-major image or its transpose by major axis),
+                               // 4: column walk (z-fastest image, the elevation rings of one yaw in neighbouring lanes)
     int32_t tile_stride;       // LDS tile of layout 2: (2 * max_length + 1) rows of tile_stride bytes (a multiple of 4)
     uint32_t tile_magic;       // ceil(2^32 / (tile_stride / 4)): row of a staged dword without an integer division
     double lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // folded clamp bounds: max(poly_min, origin), min(poly_max, origin + sizeInMeters)
@@ -143,6 +146,10 @@ struct FsFimArgs {
     // cand_perm[cand_lo + b] (cand_perm == nullptr: cand_lo + b), b < cand_count
     const int32_t *cand_perm;
     int32_t cand_lo, cand_count;
+    // cost map of the spatial sort (fs_sort.hip), or nullptr: the landmark tests a candidate took are stored under its
+    // block, costmap[cand_key[c] & (FS_COST_BINS - 1)], for the order of the next call
+    uint32_t *costmap;
+    const uint32_t *cand_key;
     // outputs (device)
     float *info_ref, *trace, *logdet, *fim21;   // fim21 may be nullptr
     int32_t *n_visible, *n_voxels;
@@ -155,7 +162,8 @@ struct FsFimArgs {
     const int32_t *rec_arrival, *rec_argmax;
     const double *rec_yaw;
     const uint8_t *rec_achievable;
-    unsigned long long *counters;   // [16]: 0 landmarks tested; per call 1 multi-pass candidates, 2 handed to the HBM tier, 3 unresolved; 4..6 their running totals; 8 / 9 work-list cursors of the LDS / HBM tier
+    unsigned long long *counters;   // [16]: 0 landmarks tested; per call 1 multi-pass candidates, 2 handed to the HBM tier, 3 unresolved; 4..6 their running totals; 8 / 9 work-list cursors of the LDS / HBM tier;
+                                    // 10 / 11 landmark tests / candidates since the last spatial sort (its cost-map mean)
     // hash tables
     int32_t hash_bits;         // LDS tier (512-thread workgroups)
     int32_t skip32;            // pass-count prediction: distinct voxels <= skip32/32 of the landmarks scanned
@@ -163,6 +171,7 @@ struct FsFimArgs {
     int32_t ghash_bits;
 };
 
+#define FS_COST_BINS   8192     // blocks of the sort's cost map (13 Morton bits)
 #define FS_CHUNK       64       // landmarks per chunk (one wave)
 #define FS_FACTOR_N    352      // (float)exp(1 - k^0.8) is exactly 0.0f from k = 337 on
 // device-side counters of a context (fs_get_counter).  FS_FIM_SCHEDULE development builds append two words per candidate
@@ -183,7 +192,8 @@ struct FsFimArgs {
 // launchers (defined in the .hip files)
 hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s);
 hipError_t fs_launch_sort_candidates(int32_t n, const double *d_goal, const FsGridDev &grid, int32_t *d_perm,
-                                    void **scratch, size_t *scratch_bytes, hipStream_t s);
+                                    void **scratch, size_t *scratch_bytes, unsigned long long *d_cost_acc,
+                                    const uint32_t **d_keys, uint32_t **d_costmap, int use_costmap, int reverse, hipStream_t s);
 hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);

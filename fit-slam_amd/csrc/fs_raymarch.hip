@@ -56,6 +56,11 @@ struct WalkLinear {
     uint32_t end;            // min(max_length_steps, abs_da): loop visits, one more after the loop
 };
 
+// WalkColumn — the same walk on the column image [y][x][z] (z runs fastest): one cache line holds 128 cells of a column,
+// so the elevation rings of one yaw — which stand above one another at every step — share a line when they sit in
+// neighbouring lanes (the kernel deals rays to lanes ring-fastest for this walk).
+struct WalkColumn : WalkLinear {};
+
 // WalkBricked — on the 8 x 8 x 2-brick copy, which has no constant strides: the walk keeps the cell coordinates and
 // applies the same body to every axis alike: an axis steps when its error term, advanced by |d_axis|, reaches
 // |d_major|.  The minor axes follow the reference's `error_b` exactly; for the major axis the term is advanced by
@@ -102,6 +107,8 @@ __device__ __forceinline__ void walk_step(WalkLinear &w)
     if ((uint32_t)w.err_c >= w.abs_da) { w.offset += (uint32_t)w.off_c; w.err_c -= (int)w.abs_da; }
 }
 
+__device__ __forceinline__ void walk_step(WalkColumn &w) { walk_step(static_cast<WalkLinear &>(w)); }
+
 __device__ __forceinline__ void walk_step(WalkBricked &w)
 {
     w.ex += (int)w.adx;
@@ -121,6 +128,13 @@ __device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkLinear &w
     if (w.offset >= (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz) { atomicMax(g.dbg, 1ull); return 256; }
 #endif
     return (int)g.cells[w.offset];
+}
+__device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkColumn &w)
+{
+#ifdef FS_RAY_BOUNDS
+    if (w.offset >= (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz) { atomicMax(g.dbg, 4ull); return 256; }
+#endif
+    return (int)g.cells_z[w.offset];
 }
 __device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkBricked &w)
 {
@@ -150,6 +164,25 @@ __device__ __forceinline__ void walk_init(WalkLinear &w, const FsGridDev &g, uin
     const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
     const int odx = sign_ref(dx), ody = sign_ref(dy) * (int)nx, odz = sign_ref(dz) * (int)(nx * ny);
     if (adx >= ady && adx >= adz) {
+        w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
+    } else if (ady >= adz) {
+        w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz;
+    } else {
+        w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody;
+    }
+    w.err_b = w.err_c = (int)(w.abs_da / 2);
+    w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
+}
+
+__device__ __forceinline__ void walk_init(WalkColumn &w, const FsGridDev &g, uint32_t x0, uint32_t y0, uint32_t z0,
+                                          uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
+{
+    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
+    const uint32_t nx = (uint32_t)g.nx, nz = (uint32_t)g.nz;
+    w.offset = (y0 * nx + x0) * nz + z0;
+    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
+    const int odx = sign_ref(dx) * (int)nz, ody = sign_ref(dy) * (int)(nx * nz), odz = sign_ref(dz);
+    if (adx >= ady && adx >= adz) {                      // the same axis order as walk_init(WalkLinear): only the strides differ
         w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
     } else if (ady >= adz) {
         w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz;
@@ -457,7 +490,11 @@ void fs_raymarch_kernel(const FsRayArgs a)
         }
     } else
     if (active && !black) {
-        for (int r = lane; r < n_rays; r += 64) {
+        constexpr bool kColumn = std::is_same<Walk, WalkColumn>::value;
+        for (int q = lane; q < n_rays; q += 64) {
+            // ray r = e * n_yaw + i.  The column walk deals the rays ring-fastest: lanes q, q + 1, .. hold the n_elev rings
+            // of one yaw, which visit cells of the same column at every step
+            const int r = kColumn ? (q % a.n_elev) * a.n_yaw + q / a.n_elev : q;
             const int i = r % a.n_yaw;
             // DEP/src/CostCalculator.cpp:42-43: wx = sx + (MAX_CAMERA_DEPTH * cos(theta))
             double wx = sx + a.dir[3 * r];
@@ -613,7 +650,8 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds_t, s, a);
-    } else if (a.bricked) hipLaunchKernelGGL(fs_raymarch_kernel<WalkBricked>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    } else if (a.bricked == 4) hipLaunchKernelGGL(fs_raymarch_kernel<WalkColumn>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    else if (a.bricked) hipLaunchKernelGGL(fs_raymarch_kernel<WalkBricked>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else hipLaunchKernelGGL(fs_raymarch_kernel<WalkLinear>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();
 }

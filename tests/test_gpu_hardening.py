@@ -62,3 +62,52 @@ def test_per_tick_entry_points_reuse_context_scratch(fs, oracle):
                 assert abs(info[i] - want) <= 1e-4 * max(1.0, abs(want))
     finally:
         s.close()
+
+
+def _same_records(a, b):
+    """integer fields bit for bit; the float32 sums to 1e-6 relative (which lane of a voxel's landmarks draws which rank is
+    decided by a race between waves, so the order of a few float additions is not reproducible from run to run)"""
+    for f in ("arrival", "argmax", "n_visible", "flags"):
+        if not np.array_equal(a[f], b[f]):
+            return False
+    if a["yaw"].tobytes() != b["yaw"].tobytes():
+        return False
+    for f in ("info_ref", "trace", "logdet"):
+        x, y = a[f].astype(np.float64), b[f].astype(np.float64)
+        fin = np.isfinite(x)
+        if not np.array_equal(fin, np.isfinite(y)) or not np.array_equal(x[~fin], y[~fin]):
+            return False
+        if not np.allclose(x[fin], y[fin], rtol=1e-6, atol=0.0):
+            return False
+    return True
+
+
+def test_processing_order_never_changes_a_record(fs):
+    """The spatial sort keeps a cost map between calls (fs_sort.hip: blocks that held expensive candidates go first) and
+    can be told to walk the blocks in reverse; the order the kernels visit the candidates in must not change a record —
+    across a cold map, a warm map, the map switched off, the reversed order and the sort switched off."""
+    w = fs.synth.make_workload("C2", n_cand=6000)
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.set_ray_params(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+                         robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+        s.upload_grid(w.cells, w.origin, w.resolution)
+        s.upload_landmarks(w.landmarks)
+        s.lookup_generate()
+        s.set_fim_params(14.0, 1.0)
+        s.max_arrival()
+        ref = s.score_candidates(w.goals, w.frontier_size, w.blacklisted)           # cold map: plain Morton order
+        assert int(ref["n_visible"].max()) > 0
+        for _ in range(3):                                                             # the map warms up over the next calls
+            assert _same_records(s.score_candidates(w.goals, w.frontier_size, w.blacklisted), ref)
+        for key, value in (("sort.reverse", 1), ("sort.costmap", 0), ("sort.reverse", 0), ("ray.sort", 0), ("ray.sort", 1), ("sort.costmap", 1)):
+            s.set_option(key, value)
+            for _ in range(2):
+                assert _same_records(s.score_candidates(w.goals, w.frontier_size, w.blacklisted), ref), (key, value)
+        # a different list on the warm map of the old one, then the old list again
+        sub = np.arange(0, 6000, 2)
+        part = s.score_candidates(w.goals[sub], w.frontier_size[sub], w.blacklisted[sub])
+        assert _same_records(part, ref[sub])
+        assert _same_records(s.score_candidates(w.goals, w.frontier_size, w.blacklisted), ref)
+    finally:
+        s.close()
