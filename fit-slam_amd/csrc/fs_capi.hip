@@ -424,15 +424,15 @@ int fill_ray_args(fs_ctx *c, FsRayArgs &a)
     // group of 16 steps, quarter-rate integer ops) where the lane-per-ray walk adds two offsets, so the kernel turns
     // instruction-bound at twice the time.  Kept as a selectable layout ("ray.layout" = 4), never chosen automatically.
     const bool span_ok = a.max_length >= 1 && a.max_length <= 1024 && (int64_t)c->n_yaw * c->n_elev <= 512;
-    if (span_ok && c->opt_layout == 4) {
+    if (span_ok && (c->opt_layout == 4 || c->opt_layout == 6)) {
         if (!c->have_cells_t) {
             const size_t total = (size_t)c->nx * (size_t)c->ny * (size_t)c->nz;
-            if (c->d_cells_t.ensure(total) != hipSuccess || fs_launch_transpose(c->d_cells.p, c->d_cells_t.p, c->nx, c->ny, c->nz, c->stream) != hipSuccess)
+            if (c->d_cells_t.ensure(total + 4) != hipSuccess || fs_launch_transpose(c->d_cells.p, c->d_cells_t.p, c->nx, c->ny, c->nz, c->stream) != hipSuccess)
                 return fail(c, FS_E_HIP, "could not stage the transposed grid image for the span walk");
             c->have_cells_t = true;
             a.grid = grid_dev(c);
         }
-        a.bricked = 3;
+        a.bricked = c->opt_layout == 6 ? 5 : 3;
     }
     // Column walk (fs_raymarch.hip, WalkColumn): the row-major walk on the z-fastest image with the elevation rings of a yaw
     // in neighbouring lanes — 16 instead of ~38 lines per wave load.  Measured on C3 (profiles/r02/c3_column_walk.json):
@@ -717,7 +717,7 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
     if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
     if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
-    FS_HIP(c, c->d_cells.ensure((size_t)total));
+    FS_HIP(c, c->d_cells.ensure((size_t)total + 4));       // (+4: the dword walk reads the aligned dword around the last cell)
     FS_HIP(c, hipMemcpyAsync(c->d_cells.p, cells, (size_t)total, hipMemcpyHostToDevice, c->stream));
     {
         const int rc = retile_grid(c, nx, ny, nz);
@@ -741,7 +741,7 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
     if ((nx & 7) || (ny & 7) || (nz & 7)) return fail(c, FS_E_INVALID, "brick upload needs dimensions that are multiples of 8");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
     if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
-    FS_HIP(c, c->d_cells.ensure((size_t)total));
+    FS_HIP(c, c->d_cells.ensure((size_t)total + 4));       // (+4: the dword walk reads the aligned dword around the last cell)
     FS_HIP(c, hipMemsetAsync(c->d_cells.p, default_value, (size_t)total, c->stream));
     if (n_bricks > 0) {
         DevBuf<int32_t> &d_xyz = c->d_brick_xyz, &d_bad = c->d_bad;
@@ -1115,7 +1115,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 5) { c->opt_layout = (int)value; return FS_OK; }
+    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 6) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);

@@ -18,7 +18,9 @@
 #include <type_traits>
 
 #define FS_RAY_WAVES 4          // candidates per workgroup
+#ifndef FS_RAY_UNROLL
 #define FS_RAY_UNROLL 4         // speculative cell loads in flight per lane
+#endif
 #define FS_TILE_BATCH 7         // dwords per lane in flight while a fan's neighbourhood is staged into LDS
 
 namespace {
@@ -26,14 +28,28 @@ namespace {
 __device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }   // std::min(a,b)
 __device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }   // std::max(a,b)
 
+// (unsigned)((w - origin) / resolution), the quotient of Costmap2D::worldToMap, without the fp64 division in the common
+// case.  Only the truncated quotient matters: t = a * (1 / res) lies within 4 ulp (< 1.5e-6 below 2^32) of the correctly
+// rounded a / res, so both truncate to the same cell unless t sits within 1e-5 of an integer — then, and for quotients
+// next to 2^32 or NaN, the division itself is evaluated (a few lanes in a million).  `q` is what the caller compares and
+// truncates: identical decisions to the division in every case.
+__device__ __forceinline__ double cell_quotient(double a, double res, double inv_res)
+{
+    const double t = a * inv_res;
+    const double fr = __builtin_amdgcn_fract(t);                       // t - floor(t), in [0, 1)
+    if (t < 4294967295.0 && fabs(fr - 0.5) < 0.5 - 1.0e-5) return t;
+    return a / res;
+}
+
 // nav2_costmap_2d::Costmap2D::worldToMap with a z axis. Quotients >= 2^32 are off-map.
 __device__ __forceinline__ bool world_to_map(const FsGridDev &g, double wx, double wy, double wz,
                                              uint32_t &mx, uint32_t &my, uint32_t &mz)
 {
     if (wx < g.ox || wy < g.oy || wz < g.oz) return false;
-    const double qx = (wx - g.ox) / g.res;
-    const double qy = (wy - g.oy) / g.res;
-    const double qz = (wz - g.oz) / g.res;
+    const double inv_res = 1.0 / g.res;                                // uniform: hoisted out of the ray loops
+    const double qx = cell_quotient(wx - g.ox, g.res, inv_res);
+    const double qy = cell_quotient(wy - g.oy, g.res, inv_res);
+    const double qz = cell_quotient(wz - g.oz, g.res, inv_res);
     if (!(qx < 4294967296.0) || !(qy < 4294967296.0) || !(qz < 4294967296.0)) return false;
     mx = (uint32_t)qx;
     my = (uint32_t)qy;
@@ -60,6 +76,12 @@ struct WalkLinear {
 // so the elevation rings of one yaw — which stand above one another at every step — share a line when they sit in
 // neighbouring lanes (the kernel deals rays to lanes ring-fastest for this walk).
 struct WalkColumn : WalkLinear {};
+
+// WalkDword — the lane-per-ray walk with FEWER loads: a ray reads the aligned 4-byte word around its cell from the image
+// whose rows run along its major axis (row-major image for x-major rays, the in-plane transpose for y-major ones) and
+// serves the following steps from that register for as long as they stay inside the word — up to four cells per load
+// for rays close to a grid axis, one per load for diagonal ones.
+struct WalkDword : WalkLinear { const uint8_t *img; };
 
 // WalkBricked — on the 8 x 8 x 2-brick copy, which has no constant strides: the walk keeps the cell coordinates and
 // applies the same body to every axis alike: an axis steps when its error term, advanced by |d_axis|, reaches
@@ -108,6 +130,7 @@ __device__ __forceinline__ void walk_step(WalkLinear &w)
 }
 
 __device__ __forceinline__ void walk_step(WalkColumn &w) { walk_step(static_cast<WalkLinear &>(w)); }
+__device__ __forceinline__ void walk_step(WalkDword &w) { walk_step(static_cast<WalkLinear &>(w)); }
 
 __device__ __forceinline__ void walk_step(WalkBricked &w)
 {
@@ -144,10 +167,28 @@ __device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkBricked &
     return (int)g.bricks[fs_brick_offset((uint32_t)g.bx, (uint32_t)g.by, (uint32_t)w.x, (uint32_t)w.y, (uint32_t)w.z)];
 }
 
-// getTracedCells from the two map cells on (Helpers.cpp:46-94): `(unsigned)(scale * abs_da)` visits
+// getTracedCells from the two map cells on (Helpers.cpp:46-94): `(unsigned)(scale * abs_da)` visits with
+// scale = min(1, max_length / hypot(d)).  Evaluated as the reference does (fp64 square root, division, product) only
+// where it could matter:
+//   * |d|^2 <= max_length^2 in integers (max_length a whole number): hypot(d) <= max_length, the quotient is >= 1 and the
+//     scale exactly 1;
+//   * otherwise s = |d_major| max_length / |d| in fp32 (v_rsq_f32; relative error < 1e-6) truncates like the fp64 chain
+//     (relative error 3e-16) unless it lies within 4e-6 s + 1e-6 of an integer — there the fp64 chain decides.
 __device__ __forceinline__ uint32_t walk_visits(int dx, int dy, int dz, uint32_t abs_da, double max_length)
 {
     const long long d2 = (long long)dx * dx + (long long)dy * dy + (long long)dz * dz;
+    // (a whole number of cells below 2^26 — the arrival fan's case; fs_trace_segments may pass any double — squares exactly)
+    const bool whole = max_length < 67108864.0 && max_length == floor(max_length);
+    if (whole && d2 < (1ll << 52) && (double)d2 <= max_length * max_length) return abs_da;
+    if (d2 < (1ll << 24) && max_length < 16777216.0) {
+        const float s = ((float)abs_da * (float)max_length) * __builtin_amdgcn_rsqf((float)d2);
+        const float fr = s - floorf(s);
+        const float guard = 4.0e-6f * s + 1.0e-6f;
+        if (fr > guard && fr < 1.0f - guard) {
+            const uint32_t max_steps = (uint32_t)s;
+            return max_steps < abs_da ? max_steps : abs_da;
+        }
+    }
     const double dist = sqrt((double)d2);          // == std::hypot(dx,dy) when dz == 0 (both correctly rounded)
     const double q = max_length / dist;
     const double scale = (dist == 0.0) ? 1.0 : ((q < 1.0) ? q : 1.0);       // std::min(1.0, max_length / dist)
@@ -185,6 +226,34 @@ __device__ __forceinline__ void walk_init(WalkColumn &w, const FsGridDev &g, uin
     if (adx >= ady && adx >= adz) {                      // the same axis order as walk_init(WalkLinear): only the strides differ
         w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
     } else if (ady >= adz) {
+        w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz;
+    } else {
+        w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody;
+    }
+    w.err_b = w.err_c = (int)(w.abs_da / 2);
+    w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
+}
+
+__device__ __forceinline__ void walk_init(WalkDword &w, const FsGridDev &g, uint32_t x0, uint32_t y0, uint32_t z0,
+                                          uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
+{
+    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
+    const uint32_t nx = (uint32_t)g.nx, ny = (uint32_t)g.ny;
+    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
+    const bool xmaj = adx >= ady && adx >= adz, ymaj = !xmaj && ady >= adz;       // the axis order of walk_init(WalkLinear)
+    // y-major rays read the image whose rows run along y: [z][x][y]
+#ifdef FS_DWORD_ROWMAJOR_ONLY
+    const bool tr = false;
+#else
+    const bool tr = ymaj;
+#endif
+    const int stx = tr ? (int)ny : 1, sty = tr ? 1 : (int)nx, stz = (int)(nx * ny);
+    w.img = tr ? g.cells_t : g.cells;
+    w.offset = z0 * (uint32_t)stz + y0 * (uint32_t)sty + x0 * (uint32_t)stx;
+    const int odx = sign_ref(dx) * stx, ody = sign_ref(dy) * sty, odz = sign_ref(dz) * stz;
+    if (xmaj) {
+        w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
+    } else if (ymaj) {
         w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz;
     } else {
         w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody;
@@ -318,6 +387,9 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
     const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
     int count = 0;
     uint32_t visits = w.end + 1;          // loop visits + the one after the loop (Helpers.cpp:29)
+#ifdef FS_RAY_ABLATE                      // development, timing only: the fan's set-up and epilogue without the walk
+    visits = visits > 1000000u ? 1u : 0u;
+#endif
     while (visits > 0) {
         // issue up to FS_RAY_UNROLL independent byte loads, then classify them in order; loads past an
         // obstacle are speculative but always inside the start/end bounding box, hence in the grid
@@ -342,6 +414,57 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
             hit = hit || (o_any && (uint32_t)(c[u] - omin) <= orange);
         }
         if (hit) break;                    // nothing is pushed after the first obstacle
+        visits -= nb;
+    }
+    return count;
+}
+
+// The same visitor over the dword walk: four steps are laid out first (offsets only), a 4-byte word is loaded for every
+// step that leaves the word of the step before it, and the cells are cut out of the words.
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkDword w)
+{
+    const int omin = a.obst_min > 0 ? a.obst_min : 0, omax = a.obst_max < 255 ? a.obst_max : 255;
+    const int tmin = a.trace_min > 0 ? a.trace_min : 0, tmax = a.trace_max < 255 ? a.trace_max : 255;
+    const bool o_any = omax >= omin, t_any = tmax >= tmin;
+    const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
+    int count = 0;
+    uint32_t visits = w.end + 1;
+    uint32_t held_idx = 0xffffffffu, held = 0u;            // the word of the last step of the previous group
+    while (visits > 0) {
+        const uint32_t nb = visits < FS_RAY_UNROLL ? visits : FS_RAY_UNROLL;
+        uint32_t off[FS_RAY_UNROLL], word[FS_RAY_UNROLL];
+        bool need[FS_RAY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            off[u] = w.offset;
+            const uint32_t before = u ? (off[u - 1] >> 2) : held_idx;
+            need[u] = (uint32_t)u < nb && (off[u] >> 2) != before;
+            if ((uint32_t)u < nb) walk_step(w);
+        }
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            word[u] = 0u;
+            if (need[u]) {
+#ifdef FS_RAY_BOUNDS
+                if ((off[u] | 3u) >= (uint32_t)a.grid.nx * (uint32_t)a.grid.ny * (uint32_t)a.grid.nz + 4u) { atomicMax(a.grid.dbg, 5ull); }
+                else
+#endif
+                word[u] = *reinterpret_cast<const uint32_t *>(w.img + (off[u] & ~3u));
+            }
+        }
+        bool hit = false;
+        uint32_t cur = held;
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            cur = need[u] ? word[u] : cur;
+            held_idx = (uint32_t)u < nb ? (off[u] >> 2) : held_idx;
+            const int c = (uint32_t)u < nb ? (int)((cur >> ((off[u] & 3u) << 3)) & 0xffu) : -1;
+            const bool traced = t_any && !hit && (uint32_t)(c - tmin) <= trange;
+            count += traced ? 1 : 0;
+            hit = hit || (o_any && (uint32_t)(c - omin) <= orange);
+        }
+        if (hit) break;
+        held = cur;
         visits -= nb;
     }
     return count;
@@ -533,8 +656,11 @@ void fs_raymarch_kernel(const FsRayArgs a)
     const int side = 2 * ri + 1;
     bool lethal = false;
     auto scan_disc = [&](auto cell_at) {
+        const float inv_side = 1.0f / (float)side;
         for (int t = lane; t < side * side; t += 64) {
-            const int dx = t / side - ri, dy = t % side - ri;
+            // t / side and t % side without the integer division: exact for t < 2^22 (side <= 2048; larger discs divide)
+            const int row = side <= 2048 ? (int)(((float)t + 0.5f) * inv_side) : t / side;
+            const int dx = row - ri, dy = (t - row * side) - ri;
             if ((double)(dx * dx + dy * dy) <= a.footprint_radius * a.footprint_radius) {
                 const uint32_t x = sxm + (uint32_t)dx, y = sym + (uint32_t)dy;
                 if (x < (uint32_t)a.grid.nx && y < (uint32_t)a.grid.ny && cell_at(x, y) == 254) lethal = true;
@@ -650,7 +776,8 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds_t, s, a);
-    } else if (a.bricked == 4) hipLaunchKernelGGL(fs_raymarch_kernel<WalkColumn>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    } else if (a.bricked == 5) hipLaunchKernelGGL(fs_raymarch_kernel<WalkDword>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    else if (a.bricked == 4) hipLaunchKernelGGL(fs_raymarch_kernel<WalkColumn>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else if (a.bricked) hipLaunchKernelGGL(fs_raymarch_kernel<WalkBricked>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else hipLaunchKernelGGL(fs_raymarch_kernel<WalkLinear>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();

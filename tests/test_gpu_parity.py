@@ -432,7 +432,7 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
             _setup_scorer(scorer, w)
             mx_o = oracle.max_arrival_information(G, P)
             want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], n_threads=8)
-            for layout in (1, 2, 3, 4, 5, 0):                   # 3: LDS-staged fan where the fan is planar, else as 0; 4: span walk
+            for layout in (1, 2, 3, 4, 5, 6, 0):                   # 3: LDS-staged fan where the fan is planar, else as 0; 4: span walk
                 scorer.set_option("ray.layout", layout)
                 assert scorer.max_arrival() == mx_o
                 _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
