@@ -242,11 +242,7 @@ __device__ __forceinline__ void walk_init(WalkDword &w, const FsGridDev &g, uint
     const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
     const bool xmaj = adx >= ady && adx >= adz, ymaj = !xmaj && ady >= adz;       // the axis order of walk_init(WalkLinear)
     // y-major rays read the image whose rows run along y: [z][x][y]
-#ifdef FS_DWORD_ROWMAJOR_ONLY
-    const bool tr = false;
-#else
     const bool tr = ymaj;
-#endif
     const int stx = tr ? (int)ny : 1, sty = tr ? 1 : (int)nx, stz = (int)(nx * ny);
     w.img = tr ? g.cells_t : g.cells;
     w.offset = z0 * (uint32_t)stz + y0 * (uint32_t)sty + x0 * (uint32_t)stx;
