@@ -683,29 +683,34 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
 #pragma unroll
             for (int j = i; j < 6; ++j) a.fim21[21 * (size_t)c + o++] = (float)F[i][j];
     }
-    // log det by Cholesky (fp64); -inf when singular: fewer than 3 landmarks can never give rank 6, and a
-    // pivot below 1e-6 of its diagonal entry is rounding noise of the fp32 sums
+    // log det from the pivots of the square-root-free Cholesky factorisation F = L D L^T (fp64): log det = log(prod d_j),
+    // one logarithm and six reciprocals instead of six logarithms, six square roots and fifteen divisions on one lane.
+    // -inf when singular: fewer than 3 landmarks can never give rank 6, and a pivot below 1e-6 of its diagonal entry is
+    // rounding noise of the fp32 sums.  (The product of six pivots of float32-range sums cannot leave the fp64 range.)
     const int nvis = (int)(S[16] + 0.5);
-    double L[6][6];
-    double ld = 0.0;
+    double Lm[6][6];                                         // unit lower triangle, strictly below the diagonal
+    double dv[6];
+    double prod = 1.0;
     bool pd = nvis >= 3;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = F[j][j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+        for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k] * dv[k];
         if (!(d > 1e-6 * F[j][j])) pd = false;
-        const double ljj = sqrt(pd ? d : 1.0);
-        L[j][j] = ljj;
-        ld += 2.0 * log(ljj);
+        const double dj = pd ? d : 1.0;
+        dv[j] = dj;
+        prod *= dj;
+        const double inv = 1.0 / dj;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double s = F[i][j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
-            L[i][j] = s / ljj;
+            for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k] * dv[k];
+            Lm[i][j] = s * inv;
         }
     }
+    const double ld = log(prod);
     const float logdet = pd ? (float)ld : -INFINITY;
     const int nvox = (int)(S[17] + 0.5);
     a.logdet[c] = logdet;
@@ -804,6 +809,6 @@ hipError_t fs_launch_fim_overflow(const FsFimArgs &a0, int pool, hipStream_t s)
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s)
 {
     if (a.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fs_fim_finish_kernel, dim3((a.n + 127) / 128), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(fs_fim_finish_kernel, dim3((a.n + 63) / 64), dim3(64), 0, s, a);      // one wave per block: 20 k candidates spread over all CUs
     return hipGetLastError();
 }
