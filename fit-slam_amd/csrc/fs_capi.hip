@@ -1240,7 +1240,7 @@ static int run_fim_tier1(fs_ctx *c, FsFimArgs &a, const int32_t *perm, int32_t l
 static int run_fim_rest(fs_ctx *c, FsFimArgs &a)
 {
     {
-        // tiers 2 and 3 exit at once unless the previous tier flagged a candidate (device-side counters)
+        // the HBM tier exits at once unless the LDS tier flagged a candidate (device-side work list)
         ScopedTimer t(c, 2);
         FS_HIP(c, fs_launch_fim_overflow(a, fs_ctx::kPool, c->stream));
     }

@@ -5,8 +5,8 @@
 // of FisherInformationHelpers.cpp:71-123, batched over candidate poses.
 //
 // Data: the landmark cloud is staged once (fs_upload_landmarks) in k-d leaf order as SoA fp32 and cut
-// into chunks of 64 consecutive landmarks, each with a bounding sphere.  One workgroup scores one
-// candidate:
+// into chunks of 64 consecutive landmarks, each with a bounding sphere.  Persistent workgroups (two per CU) pull
+// candidates from a device-side cursor over the processing order (fs_sort.hip); per candidate:
 //   1. cull   — chunk k belongs to wave (k mod waves); every lane tests one chunk sphere against the
 //               visibility volume (range sphere + cone, conservative) and the wave walks the ballot mask.  Only a few per cent of a 512^3
 //               map's cloud survives, so the per-landmark work drops by an order of magnitude while the
@@ -23,8 +23,8 @@
 //               count is the landmark's rank k in its voxel -> crowding factor exp(1 - k^0.8)
 //               (FisherInfoManager.hpp:102-106).  Same multiset of (info_v, k) terms as the reference's
 //               sequential loop.  Unit-weight 6x6 FIM via the block form [[P/n^2,-S/n^2],[S/n^2,P]].
-//   5. reduce — wave shuffles, LDS across waves, fp64 per quantity; fs_fim_finish_kernel assembles F,
-//               trace and the Cholesky log det.
+//   5. reduce — DPP row reductions, LDS across waves, fp64 per quantity; fs_fim_finish_kernel assembles F,
+//               trace and the log det (pivots of the square-root-free Cholesky factorisation).
 // Hash tables: 2^14 LDS slots per 512-thread workgroup (two workgroups per CU).  A candidate predicted to hold more
 // distinct voxels than the table takes is scored by the same workgroup in 2, 4 or 8 voxel-partitioned PASSES; only a
 // real overflow hands it to the table in HBM.  Scan + scatter-count has no dense contraction: no MFMA.
@@ -53,7 +53,7 @@
 #ifndef FS_T1_WAVES_PER_EU
 #define FS_T1_WAVES_PER_EU ((FS_T1_THREADS * 2 + 255) / 256)      // two workgroups per CU, four SIMDs
 #endif
-#define FS_T2_THREADS 1024
+#define FS_HBM_THREADS 1024    // workgroup of the HBM tier (fs_fim_tier3_kernel)
 
 #ifdef FS_FIM_BOUNDS   // development: every global access is range-checked, violations are recorded in counters[30] and skipped
 #define FS_BOUND(ok, code) ((ok) ? true : (atomicMax(&a.counters[30], (unsigned long long)(code)), false))
@@ -781,11 +781,11 @@ template <bool TABLE_FULL>
 hipError_t launch_overflow(FsFimArgs &a, int pool, hipStream_t s)
 {
     const int blocks = a.n < pool ? a.n : pool;
-    const size_t lds3 = lds_bytes<FS_T2_THREADS>(0, true, a.n_chunks, &a.n_groups);
-    auto kernel3 = fs_fim_tier3_kernel<FS_T2_THREADS, TABLE_FULL>;
+    const size_t lds3 = lds_bytes<FS_HBM_THREADS>(0, true, a.n_chunks, &a.n_groups);
+    auto kernel3 = fs_fim_tier3_kernel<FS_HBM_THREADS, TABLE_FULL>;
     hipError_t e = allow_lds(kernel3, lds3);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel3, dim3(blocks), dim3(FS_T2_THREADS), lds3, s, a);
+    hipLaunchKernelGGL(kernel3, dim3(blocks), dim3(FS_HBM_THREADS), lds3, s, a);
     return hipGetLastError();
 }
 

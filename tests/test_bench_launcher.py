@@ -39,6 +39,9 @@ def test_defaults_are_the_headline_configuration():
     b = _bench_module()
     a = b.parse([])
     assert (a.gpus, a.workload, a.scaling) == (1, "C3", "weak") and a.repeats >= 5
+    # one stream, batches strictly back to back: with more contexts the FIM kernels of two batches share the CUs and the
+    # per-launch durations behind `roofline` stop measuring the kernel
+    assert a.pipeline == 1 and b.parse(["--pipeline", "2"]).pipeline == 2
 
 
 def test_two_ranks_are_spawned_and_rank0_line_is_relayed():
