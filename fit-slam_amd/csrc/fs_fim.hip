@@ -63,10 +63,12 @@
 
 namespace {
 
+typedef float fs_f2 __attribute__((ext_vector_type(2)));
 struct Acc {
     float info;
-    float A[6];                   // sum P        , P = I - p^ p^T       (xx, xy, xz, yy, yz, zz)
-    float B[6];                   // sum P / n^2
+    // (sum P, sum P / n^2) per entry of P = I - p^ p^T (xx, xy, xz, yy, yz, zz): a pair per entry, so that one packed
+    // v_pk_fma_f32 — (A, B) += v * (1, 1/n^2) — accumulates both (gfx950 issues it like a scalar fp32 instruction)
+    fs_f2 AB[6];
     float s[3];                   // sum p / n^2
     int nvis, nvox;
 };
@@ -160,8 +162,9 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         const float qx = px * q, qy = py * q, qz = pz * q;
         const float xx = px * qx, yy = py * qy, zz = pz * qz;
         const float v[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
+        const fs_f2 one_q = {1.0f, q};
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { acc.A[i] += v[i]; acc.B[i] += v[i] * q; }
+        for (int i = 0; i < 6; ++i) acc.AB[i] = __builtin_elementwise_fma((fs_f2){v[i], v[i]}, one_q, acc.AB[i]);
         acc.s[0] += qx; acc.s[1] += qy; acc.s[2] += qz;
     }
 
@@ -459,7 +462,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         Acc acc;
         acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { acc.A[i] = 0.f; acc.B[i] = 0.f; }
+        for (int i = 0; i < 6; ++i) acc.AB[i] = (fs_f2){0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc.s[i] = 0.f;
         int qcount = 0;                                            // wave-uniform
@@ -557,7 +560,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         float vals[FS_NACC];
         vals[0] = acc.info;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { vals[1 + i] = acc.A[i]; vals[7 + i] = acc.B[i]; }
+        for (int i = 0; i < 6; ++i) { vals[1 + i] = acc.AB[i].x; vals[7 + i] = acc.AB[i].y; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) vals[13 + i] = acc.s[i];
         vals[16] = (float)acc.nvis;     // exact: < 2^24 per lane
