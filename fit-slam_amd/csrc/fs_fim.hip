@@ -69,7 +69,7 @@ struct Acc {
     // (sum P, sum P / n^2) per entry of P = I - p^ p^T (xx, xy, xz, yy, yz, zz): a pair per entry, so that one packed
     // v_pk_fma_f32 — (A, B) += v * (1, 1/n^2) — accumulates both (gfx950 issues it like a scalar fp32 instruction)
     fs_f2 AB[6];
-    float s[3];                   // sum p / n^2
+    fs_f2 s01; float s2;          // sum p / n^2
     int nvis, nvox;
 };
 
@@ -159,13 +159,16 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
         // (hardware reciprocal, 1 ulp: these sums only feed trace / log det / the 6x6, all held to 1e-4)
         const float q = (active && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f;
-        const float qx = px * q, qy = py * q, qz = pz * q;
-        const float xx = px * qx, yy = py * qy, zz = pz * qz;
+        const fs_f2 pxy = {px, py};
+        const fs_f2 qxy = pxy * (fs_f2){q, q};
+        const fs_f2 xxyy = pxy * qxy;
+        const float qy = qxy.y, qz = pz * q;
+        const float xx = xxyy.x, yy = xxyy.y, zz = pz * qz;
         const float v[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
         const fs_f2 one_q = {1.0f, q};
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc.AB[i] = __builtin_elementwise_fma((fs_f2){v[i], v[i]}, one_q, acc.AB[i]);
-        acc.s[0] += qx; acc.s[1] += qy; acc.s[2] += qz;
+        acc.s01 += qxy; acc.s2 += qz;
     }
 
     uint32_t rank = 0u;
@@ -463,8 +466,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc.AB[i] = (fs_f2){0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) acc.s[i] = 0.f;
+        acc.s01 = (fs_f2){0.f, 0.f}; acc.s2 = 0.f;
         int qcount = 0;                                            // wave-uniform
         const unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
 
@@ -561,8 +563,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         vals[0] = acc.info;
 #pragma unroll
         for (int i = 0; i < 6; ++i) { vals[1 + i] = acc.AB[i].x; vals[7 + i] = acc.AB[i].y; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) vals[13 + i] = acc.s[i];
+        vals[13] = acc.s01.x; vals[14] = acc.s01.y; vals[15] = acc.s2;
         vals[16] = (float)acc.nvis;     // exact: < 2^24 per lane
         vals[17] = (float)acc.nvox;
 #pragma unroll
