@@ -107,7 +107,11 @@ __device__ __forceinline__ uint32_t voxel_key(const FsFimArgs &a, bool active, f
     jx -= a.jx0; jy -= a.jy0; jz -= a.jz0;
     in_table = active && (unsigned)jx < (unsigned)a.tx && (unsigned)jy < (unsigned)a.ty && (unsigned)jz < (unsigned)a.tz;
     // table extents are < 2^11 each and the cell count < 2^21 (FS_MAX_TABLE_CELLS): 24-bit multiplies are exact
-    return in_table ? (uint32_t)__umul24((uint32_t)__umul24((uint32_t)jx, (uint32_t)a.ty) + (uint32_t)jy, (uint32_t)a.tz) + (uint32_t)jz : 0u;
+    // (two v_mad_u32_u24 — left to itself the compiler widens the first product to a quarter-rate v_mad_u64_u32 under an exec mask)
+    uint32_t row, cell;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(jx), "s"(a.ty), "v"(jy));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cell) : "v"(row), "s"(a.tz), "v"(jz));
+    return in_table ? cell : 0u;
 }
 
 // Which of a candidate's n_parts (a power of two) scoring passes owns a landmark: the x index of its voxel, exactly as
@@ -150,8 +154,8 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     uint32_t hb = hash_key(key, bits - 2);
     (void)FS_BOUND(hb <= bmask, 5);
     hb &= bmask;      // whatever the hash returns, the bucket index stays inside the table ("the 06:07 abort")
-    uint4 bk = make_uint4(0u, 0u, 0u, 0u);
-    if (valid) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
+    // (read by every lane: a lane without a voxel reads the bucket of key 0 and ignores it — cheaper than masking the load)
+    uint4 bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
 
     // ---- unit-weight FIM block sums, F(p) = [[P/n^2, -S/n^2],[S/n^2, P]]; P's diagonal as a
     // sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector has no Jacobian.
@@ -190,7 +194,7 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         const uint32_t cur_match = m0 ? w0 : (m1 ? w1 : (m2 ? w2 : w3));
         const uint32_t jm = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u));
         // slots fill in order: the first empty one is the number of occupied ones
-        const uint32_t used = (w0 != 0u ? 1u : 0u) + (w1 != 0u ? 1u : 0u) + (w2 != 0u ? 1u : 0u) + (w3 != 0u ? 1u : 0u);
+        const uint32_t used = (w0 < 1u ? w0 : 1u) + (w1 < 1u ? w1 : 1u) + (w2 < 1u ? w2 : 1u) + (w3 < 1u ? w3 : 1u);   // v_min_u32 x 4
         const bool can_insert = !has_match && used < 4u;
         uint32_t *slot = table + (hb << 2) + (has_match ? jm : (used < 4u ? used : 0u));
         uint32_t prev = 0xffffffffu;
