@@ -386,9 +386,30 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
 #ifdef FS_RAY_ABLATE                      // development, timing only: the fan's set-up and epilogue without the walk
     visits = visits > 1000000u ? 1u : 0u;
 #endif
+    // full groups of FS_RAY_UNROLL visits first: every visit of the group exists, so the loads and steps need no per-step
+    // bounds (one exec mask per group instead of one per step); the remainder (< FS_RAY_UNROLL visits) goes through the guarded
+    // loop below.  Loads past an obstacle are speculative but always inside the start/end bounding box, hence in the grid.
+    bool stopped = false;
+    while (visits >= FS_RAY_UNROLL) {
+        int c[FS_RAY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            c[u] = walk_cell(a.grid, w);
+            walk_step(w);                   // (the step behind a ray's very last visit leads nowhere that is read)
+        }
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            const bool traced = t_any && !hit && (uint32_t)(c[u] - tmin) <= trange;
+            count += traced ? 1 : 0;
+            hit = hit || (o_any && (uint32_t)(c[u] - omin) <= orange);
+        }
+        if (hit) { stopped = true; break; }  // nothing is pushed after the first obstacle
+        visits -= FS_RAY_UNROLL;
+    }
+    if (stopped) visits = 0;
     while (visits > 0) {
-        // issue up to FS_RAY_UNROLL independent byte loads, then classify them in order; loads past an
-        // obstacle are speculative but always inside the start/end bounding box, hence in the grid
+        // the last, partial group: up to FS_RAY_UNROLL - 1 independent byte loads, then classify them in order
         int c[FS_RAY_UNROLL];
         const uint32_t nb = visits < FS_RAY_UNROLL ? visits : FS_RAY_UNROLL;
 #pragma unroll
