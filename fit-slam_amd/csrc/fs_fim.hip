@@ -289,11 +289,16 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     float *lfac = Lds<THREADS>::factor(lds);
     float *qx = Lds<THREADS>::queue(lds, wave), *qy = qx + FS_QCAP, *qz = qy + FS_QCAP;
 
-    auto fetch = [&]() -> int {                                    // thread 0 only
-        const int i = (int)atomicAdd(work.counter, 1ull);
+    // The LDS tier hands every workgroup its first two items by position (b and b + grid): two dependent device-scope
+    // atomics less before the first landmark is tested; the shared cursor then counts from 2 * grid.
+    const int preassigned = GLOBAL_TABLE ? 0 : 2 * (int)gridDim.x;
+    auto item = [&](int i) -> int {
         if (i >= work.count) return -1;
         const int cid = work.list ? work.list[work.lo + i] : work.lo + i;
         return FS_BOUND(cid >= 0 && cid < a.n, 2) ? cid : -1;
+    };
+    auto fetch = [&]() -> int {                                    // thread 0 only
+        return item((int)atomicAdd(work.counter, 1ull) + preassigned);
     };
 
     // ---- 1. cull: chunk k belongs to wave (k mod WAVES); one sphere per lane, 64 chunks of the wave per pass, four
@@ -375,8 +380,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // Work items are fetched two candidates ahead: the atomic's round trip (and the dependent list lookup) is issued by
     // thread 0 at the top of an iteration and only consumed after that iteration's scoring loop.
     if (tid == 0) {
-        const int first = fetch();
-        sh_next[0] = first; sh_next[1] = first >= 0 ? fetch() : -1;
+        const int first = GLOBAL_TABLE ? fetch() : item((int)blockIdx.x);
+        sh_next[0] = first;
+        sh_next[1] = first >= 0 ? (GLOBAL_TABLE ? fetch() : item((int)blockIdx.x + (int)gridDim.x)) : -1;
         sh_overflow[0] = 0; sh_overflow[1] = 0;
     }
     for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
