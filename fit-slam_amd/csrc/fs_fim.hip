@@ -385,6 +385,11 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         sh_next[1] = first >= 0 ? (GLOBAL_TABLE ? fetch() : item((int)blockIdx.x + (int)gridDim.x)) : -1;
         sh_overflow[0] = 0; sh_overflow[1] = 0;
     }
+    // (the LDS tier knows its first item without the LDS round trip: its pose record is requested before the barrier, together
+    // with the factor table and the resident spheres)
+    const int first_item = GLOBAL_TABLE ? -1 : __builtin_amdgcn_readfirstlane(item((int)blockIdx.x));
+    PoseLoad first_pose;
+    if (!GLOBAL_TABLE && first_item >= 0) first_pose = load_pose(first_item);
     for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
     __syncthreads();
     // values read back from LDS flags are the same in every lane; readfirstlane tells the compiler so, which keeps the
@@ -396,7 +401,10 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     for (int i = 0; i < 9; ++i) Rn[i] = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) tn[i] = 0.f;
-    if (cur >= 0) cull(load_pose(cur), 0, Rn, tn);
+    if (cur >= 0) {
+        if (GLOBAL_TABLE) first_pose = load_pose(cur);
+        cull(first_pose, 0, Rn, tn);
+    }
     __syncthreads();
 
 #ifdef FS_FIM_STAMPS
