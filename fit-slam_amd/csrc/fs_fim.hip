@@ -377,8 +377,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     };
 
     // ---- prologue: first candidate, factor table
-    // Work items are fetched two candidates ahead: the atomic's round trip (and the dependent list lookup) is issued by
-    // thread 0 at the top of an iteration and only consumed after that iteration's scoring loop.
+    // Work items are fetched two candidates ahead, by thread 0, behind an iteration's scoring loop (see there).
     if (tid == 0) {
         const int first = GLOBAL_TABLE ? fetch() : item((int)blockIdx.x);
         sh_next[0] = first;
@@ -419,8 +418,6 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         unsigned long long t_cand;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_cand) :: "memory");
 #endif
-        int ahead = -1;
-        if (tid == 0 && sh_next[buf ^ 1] >= 0) ahead = fetch();    // the candidate after the next one; stored below
         int wg_tested = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) wg_tested += sh_wave_tested[buf][w];
@@ -572,8 +569,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         }   // passes
 
         // ---- the next candidate's cull fills the time this wave would otherwise wait for the slower ones
-        if (tid == 0) sh_next[buf] = ahead;                        // read by the next iteration after its first barrier
+        // The work item after the next one is drawn HERE, not at the top of the iteration: the device-scope atomic (a round trip
+        // of microseconds) is in flight during the cull, and the wait for it and for the list lookup falls into the time this
+        // wave would spend at the reduction barrier anyway — at the top, between the two barriers, it held up the whole
+        // workgroup once per candidate.
+        const bool draw = tid == 0 && nxt >= 0;
+        unsigned long long ticket = 0ull;
+        if (draw) ticket = atomicAdd(work.counter, 1ull);
         if (nxt >= 0) cull(next_pose, buf ^ 1, Rn, tn);
+        if (tid == 0) sh_next[buf] = draw ? item((int)ticket + preassigned) : -1;   // read by the next iteration after its first barrier
 
         FS_STAMP(4);
         // ---- 5. reduce: DPP within the wave, then across waves through LDS
