@@ -308,13 +308,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // the previous candidate's scoring loop), and the chunk spheres a lane tests are the same for every candidate —
     // chunk (g * STRIDE + lane * WAVES + wave) for pass g — so the first four passes' spheres stay in registers for the
     // whole persistent loop: on clouds of up to 4 * THREADS chunks (C3: 1563) a cull issues no load at all.
-    struct PoseLoad { float4 r0, r1, r2; int status; };
+    struct PoseLoad { float4 r0, r1, r2; int status; uint32_t key; };   // key: the candidate's sort key (thread 0; cost map)
     auto load_pose = [&](int c) -> PoseLoad {
         PoseLoad p;
         if (!FS_BOUND(c >= 0 && c < a.n, 6)) c = 0;
         p.status = a.status ? a.status[c] : FS_STATUS_OK;
         const float4 *rt = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c);
         p.r0 = rt[0]; p.r1 = rt[1]; p.r2 = rt[2];
+        p.key = (!GLOBAL_TABLE && tid == 0 && a.costmap) ? a.cand_key[c] : 0u;     // requested here, used a whole candidate later
         return p;
     };
     constexpr bool RESIDENT_SPHERES = !GLOBAL_TABLE;              // (the 1024-thread HBM tier has no registers to spare)
@@ -395,6 +396,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // whole persistent loop's control flow scalar (no exec-mask loops, loop-carried counters in SGPRs)
     int cur = __builtin_amdgcn_readfirstlane(sh_next[0]);
     int buf = 0;
+    uint32_t cur_key = 0u;                                          // thread 0: sort key of `cur`
     float Rn[9], tn[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) Rn[i] = 0.f;
@@ -402,6 +404,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     for (int i = 0; i < 3; ++i) tn[i] = 0.f;
     if (cur >= 0) {
         if (GLOBAL_TABLE) first_pose = load_pose(cur);
+        cur_key = first_pose.key;
         cull(first_pose, 0, Rn, tn);
     }
     __syncthreads();
@@ -468,7 +471,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         FS_STAMP(1);
         const int nxt = __builtin_amdgcn_readfirstlane(sh_next[buf ^ 1]);
         PoseLoad next_pose;                                        // in flight during this candidate's scoring loop
-        if (nxt >= 0) next_pose = load_pose(nxt);
+        uint32_t next_key = 0u;
+        if (nxt >= 0) { next_pose = load_pose(nxt); next_key = next_pose.key; }
         if (tid == 0) sh_overflow[buf ^ 1] = 0;                    // flag of the candidate after this one
         // (the flag is read and written with workgroup-scope atomics on the LDS array itself: a `volatile int *` into it
         // decays to a generic pointer, and FLAT accesses count on vmcnt — every read drained the landmark prefetch)
@@ -609,7 +613,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             a.overflow[c] = failed ? fail_code : 0u;                  // the HBM tier re-scores flagged candidates
             if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);   // landmarks tested (M_tested), summed by the finish kernel
             // what this candidate cost, filed under its block of the map for the order of the next call (fs_sort.hip)
-            if (!GLOBAL_TABLE && a.costmap) atomicMax(&a.costmap[a.cand_key[c] & (FS_COST_BINS - 1)], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);
+            // (the key was requested with the pose record: a load here would hold thread 0 — and with it the workgroup's next
+            // barrier — for a memory round trip)
+            if (!GLOBAL_TABLE && a.costmap) atomicMax(&a.costmap[cur_key & (FS_COST_BINS - 1)], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);
             if (!GLOBAL_TABLE && n_parts > 1 && !failed) atomicAdd(&a.counters[1], 1ull);   // scored in several passes
             if (failed && !GLOBAL_TABLE) {
                 const unsigned long long slot = atomicAdd(&a.counters[2], 1ull);
@@ -619,6 +625,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             }
         }
         cur = nxt;
+        cur_key = next_key;
         buf ^= 1;
         FS_STAMP(7);
 #ifdef FS_FIM_SCHEDULE
