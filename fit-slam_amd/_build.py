@@ -26,6 +26,7 @@ RESOURCES = os.path.join(CSRC, "kernel_resources.json")
 RESOURCE_LIMITS = {"fs_fim_kernel": (128, 0)}
 if os.environ.get("FS_BOUNDS"):           # development: range-checked global accesses in the FIM (counter 30) and ray (29) kernels
     HIPCC_FLAGS += ["-DFS_FIM_BOUNDS", "-DFS_RAY_BOUNDS"]
+    RESOURCE_LIMITS = {}                  # (the checks cost registers: a few bytes of scratch are fine in this build)
 if os.environ.get("FS_FIM_ABLATE"):       # development: timing-only ablations of the FIM worker (wrong results; see fs_fim.hip)
     HIPCC_FLAGS.append("-DFS_FIM_ABLATE=" + os.environ["FS_FIM_ABLATE"])
 if os.environ.get("FS_T1_WAVES_PER_EU"):  # development: occupancy target of the FIM worker's register allocation
