@@ -487,6 +487,16 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkDword w)
     return count;
 }
 
+// Every wave of the kernel below works on LDS of its own (per-yaw sums, tile, descriptors): what it wrote must be visible to
+// its own later reads — which the LDS guarantees per wave, in program order — so the points where that matters need the
+// compiler to keep the order, not a workgroup barrier.  (With s_barrier there the four fans of a workgroup waited for the
+// slowest of them twice, and a finished wave kept its slot until the whole workgroup was done.)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename Walk>
 __global__ __launch_bounds__(FS_RAY_WAVES * 64)
 void fs_raymarch_kernel(const FsRayArgs a)
@@ -506,7 +516,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
     const int n_rays = a.n_yaw * a.n_elev;
 
     for (int i = lane; i < a.n_yaw; i += 64) ysum[i] = 0;
-    __syncthreads();
+    wave_lds_fence();
 
     bool black = false;
     double sx = 0, sy = 0, sz = 0;
@@ -527,7 +537,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
         tg.x0 = ((int)sxm - L) & ~3;                        // floor to a multiple of 4 (also for negative values)
         tg.y0 = (int)sym - L;
         if (start_ok && !black) stage_tile(a, tg, szm, lane);
-        __syncthreads();                                    // the tile is written and read by the same wave; all waves pass here
+        wave_lds_fence();                                    // the tile is written and read by the same wave
     }
     if constexpr (kSpan) {
         // ---- phase 1: every lane prepares the descriptors of its rays (fp64 end points exactly as below)
@@ -574,7 +584,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
                 dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
             }
         }
-        __syncthreads();                                    // descriptors are written and read by the same wave; all waves pass here
+        wave_lds_fence();                                    // descriptors are written and read by the same wave
         // ---- phase 2: four rays per wave instruction, sixteen consecutive steps each
         if (active && !black) {
             const int omin = a.obst_min > 0 ? a.obst_min : 0, omax = a.obst_max < 255 ? a.obst_max : 255;
@@ -654,7 +664,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
         }
     }
     const bool any_fail = __any(fail);           // :50-55 — the first failing ray aborts the candidate
-    __syncthreads();
+    wave_lds_fence();
     if (!active) return;
 
     uint8_t ach = a.achievable_in ? a.achievable_in[c] : (uint8_t)1;
