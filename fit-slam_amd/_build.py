@@ -38,6 +38,8 @@ if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counter
     HIPCC_FLAGS.append("-DFS_FIM_STAMPS")
 if os.environ.get("FS_RAY_UNROLL"):       # development: speculative cell loads in flight per lane of the ray walks (default 4; 8: -1 %, 2: +4 % on C3)
     HIPCC_FLAGS.append("-DFS_RAY_UNROLL=" + os.environ["FS_RAY_UNROLL"])
+if os.environ.get("FS_RAY_WAVES"):        # development: fans (waves) per workgroup of the ray-march kernel (default 4)
+    HIPCC_FLAGS.append("-DFS_RAY_WAVES=" + os.environ["FS_RAY_WAVES"])
 if os.environ.get("FS_RAY_ABLATE"):       # development, timing only: ray kernels without the walk (set-up + epilogue: 0.056 of 0.232 ms on C3)
     HIPCC_FLAGS.append("-DFS_RAY_ABLATE")
 if os.environ.get("FS_FIM_SCHEDULE"):     # development: per-candidate start / duration / workgroup of the persistent FIM grid (tools/fim_schedule.py)

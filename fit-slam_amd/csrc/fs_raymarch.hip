@@ -17,7 +17,9 @@
 
 #include <type_traits>
 
+#ifndef FS_RAY_WAVES
 #define FS_RAY_WAVES 4          // candidates per workgroup
+#endif
 #ifndef FS_RAY_UNROLL
 #define FS_RAY_UNROLL 4         // speculative cell loads in flight per lane
 #endif
