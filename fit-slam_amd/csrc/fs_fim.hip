@@ -282,7 +282,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // loop conditions and address bases in scalar registers instead of exec-masked vector code
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     __shared__ int sh_overflow[2], sh_wave_tested[2][WAVES], sh_next[2];
-    __shared__ float sh_red[WAVES * FS_NACC];
+    __shared__ __attribute__((aligned(16))) float sh_red[WAVES * FS_NACC];
 
     const float4 *__restrict__ spheres = reinterpret_cast<const float4 *>(a.spheres);
     const float *__restrict__ LX = a.lx, *__restrict__ LY = a.ly, *__restrict__ LZ = a.lz;
@@ -596,7 +596,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         for (int i = 0; i < FS_NACC; ++i) vals[i] = wave_sum_dpp(vals[i]);
         if (lane == 63) {
 #pragma unroll
-            for (int i = 0; i < FS_NACC; ++i) sh_red[wave * FS_NACC + i] = vals[i];
+            for (int i = 0; i < FS_NACC; ++i) sh_red[i * WAVES + wave] = vals[i];     // [quantity][wave]: one thread reads its row with wide loads
         }
         FS_STAMP(5);
         __syncthreads();
@@ -605,8 +605,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // fs_fim_finish_kernel so that this kernel carries no private arrays
         const bool failed = __builtin_amdgcn_readfirstlane(sh_overflow[buf]) != 0;
         if (tid < FS_NACC && !failed) {
+            float part[WAVES];
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) part[w] = sh_red[tid * WAVES + w];
             double x = 0.0;
-            for (int w = 0; w < WAVES; ++w) x += (double)sh_red[w * FS_NACC + tid];
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) x += (double)part[w];
             if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + tid] = x;
         }
         if (tid == 0) {
