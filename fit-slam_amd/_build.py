@@ -36,6 +36,8 @@ if os.environ.get("FS_T1_THREADS"):       # development: workgroup size of the F
     HIPCC_FLAGS.append("-DFS_T1_THREADS=" + os.environ["FS_T1_THREADS"])
 if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counters of the FIM worker in counters 16..24
     HIPCC_FLAGS.append("-DFS_FIM_STAMPS")
+    if os.environ.get("FS_FIM_STAMPS") == "wave":   # ... and the barrier wait / scoring time by wave index (tools/fim_stamps.py prints them)
+        HIPCC_FLAGS.append("-DFS_FIM_STAMPS_PER_WAVE")
 if os.environ.get("FS_RAY_UNROLL"):       # development: speculative cell loads in flight per lane of the ray walks (default 4; 8: -1 %, 2: +4 % on C3)
     HIPCC_FLAGS.append("-DFS_RAY_UNROLL=" + os.environ["FS_RAY_UNROLL"])
 if os.environ.get("FS_RAY_WAVES"):        # development: fans (waves) per workgroup of the ray-march kernel (default 4)

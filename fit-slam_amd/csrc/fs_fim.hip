@@ -645,6 +645,10 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     if (lane == 0 && !GLOBAL_TABLE && THREADS == FS_T1_THREADS) {
         for (int k = 0; k < 10; ++k) atomicAdd(&a.counters[16 + k], st[k]);
         atomicAdd(&a.counters[31], 1ull);
+#ifdef FS_FIM_STAMPS_PER_WAVE   // wait at the reduction barrier / scoring time by wave index (counters 32.. of an enlarged block)
+        atomicAdd(&a.counters[32 + wave], st[6]);
+        atomicAdd(&a.counters[48 + wave], st[2] + st[3]);
+#endif
     }
 #endif
 }

@@ -178,7 +178,9 @@ struct FsFimArgs {
 // (< FS_SCHEDULE_MAX): the 100 MHz tick at which a workgroup of the persistent FIM grid started it, and
 // duration | workgroup << 32 | passes << 56 (tools/fim_schedule.py).
 #define FS_SCHEDULE_MAX 32768
-#ifdef FS_FIM_SCHEDULE
+#if defined(FS_FIM_STAMPS_PER_WAVE)
+#define FS_N_COUNTERS 80
+#elif defined(FS_FIM_SCHEDULE)
 #define FS_N_COUNTERS (32 + 2 * FS_SCHEDULE_MAX)
 #else
 #define FS_N_COUNTERS 32

@@ -23,3 +23,13 @@ for k in range(8):
     print("  %-28s %9.0f  %5.1f %%" % (names[k], st[k] / n_iter, 100.0 * st[k] / tot))
 print("  of the scoring loop: %.0f ticks in %.2f score calls (%.0f each), the rest = chunk tests + compaction" % (
     st[8] / n_iter, st[9] / n_iter, st[8] / max(1, st[9])))
+
+try:
+    per_wait = [sc.get_counter(32 + k) for k in range(8)]
+    per_score = [sc.get_counter(48 + k) for k in range(8)]
+    n_c = reps * w.goals.shape[0]
+    print("by wave index (FS_FIM_STAMPS=wave builds): wait at the reduction barrier / scoring + flush, ticks per candidate")
+    for k in range(8):
+        print("  wave %d: wait %7.0f   scoring %7.0f" % (k, per_wait[k] / n_c, per_score[k] / n_c))
+except Exception as e:
+    pass
