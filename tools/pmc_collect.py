@@ -215,6 +215,9 @@ def main():
                 res["valu_issue_utilisation_vs_4_wave_peak"] = res["valu_wave_insts_per_cycle_per_simd"] / peak4
         if cyc and "SQ_INSTS_SALU" in fim:
             res["salu_insts_per_cycle_per_cu"] = fim["SQ_INSTS_SALU"] / (256 * cyc)
+            # every instruction class together: what a SIMD's four waves issue per cycle (each wave issues one at a time)
+            res["all_insts_per_cycle_per_simd"] = sum(fim.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
+                                                                                "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM")) / (n_simd * cyc)
         wc = fim.get("SQ_WAVE_CYCLES")
         if wc:
             for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS",
