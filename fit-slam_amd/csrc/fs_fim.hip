@@ -187,12 +187,13 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
             if (!done) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
         }
         const uint32_t w0 = bk.x, w1 = bk.y, w2 = bk.z, w3 = bk.w;
-        // a slot holds my voxel iff it agrees with the tag above the count bits (an empty slot never does: tag >= 2^11)
-        const bool m0 = (w0 ^ tag) <= FS_SLOT_CNT_MASK, m1 = (w1 ^ tag) <= FS_SLOT_CNT_MASK;
-        const bool m2 = (w2 ^ tag) <= FS_SLOT_CNT_MASK, m3 = (w3 ^ tag) <= FS_SLOT_CNT_MASK;
-        const bool has_match = m0 || m1 || m2 || m3;
-        const uint32_t cur_match = m0 ? w0 : (m1 ? w1 : (m2 ? w2 : w3));
-        const uint32_t jm = m0 ? 0u : (m1 ? 1u : (m2 ? 2u : 3u));
+        // a slot holds my voxel iff it agrees with the tag above the count bits, i.e. slot ^ tag is a bare count (an empty
+        // slot never does: tag >= 2^11); at most one slot can, so the smallest of the four differences is that count
+        const uint32_t x0 = w0 ^ tag, x1 = w1 ^ tag, x2 = w2 ^ tag, x3 = w3 ^ tag;
+        const uint32_t xm3 = x0 < x1 ? (x0 < x2 ? x0 : x2) : (x1 < x2 ? x1 : x2);                       // v_min3_u32
+        const uint32_t xmin = xm3 < x3 ? xm3 : x3;
+        const bool has_match = xmin <= FS_SLOT_CNT_MASK;
+        const uint32_t jm = x0 == xmin ? 0u : (x1 == xmin ? 1u : (x2 == xmin ? 2u : 3u));
         // slots fill in order: the first empty one is the number of occupied ones
         const uint32_t used = (w0 < 1u ? w0 : 1u) + (w1 < 1u ? w1 : 1u) + (w2 < 1u ? w2 : 1u) + (w3 < 1u ? w3 : 1u);   // v_min_u32 x 4
         const bool can_insert = !has_match && used < 4u;
@@ -200,10 +201,11 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         uint32_t prev = 0xffffffffu;
         if (!done && can_insert) prev = atomicCAS(slot, 0u, tag | 1u);    // 0: this lane created the entry
         const bool won = !done && can_insert && prev == 0u;
-        const bool late = !done && can_insert && prev != 0u && (prev ^ tag) <= FS_SLOT_CNT_MASK;   // my voxel just arrived there
+        const uint32_t xprev = prev ^ tag;
+        const bool late = !done && can_insert && prev != 0u && xprev <= FS_SLOT_CNT_MASK;   // my voxel just arrived there
         const bool do_add = !done && (has_match || late);
-        const uint32_t cur = has_match ? cur_match : prev;
-        const bool sat = do_add && (cur & FS_SLOT_CNT_MASK) >= FS_SLOT_CNT_SAT;                      // factor is 0.0f out there anyway
+        const uint32_t cnt = has_match ? xmin : xprev;                     // the entry's count before my add
+        const bool sat = do_add && cnt >= FS_SLOT_CNT_SAT;                 // factor is 0.0f out there anyway
         uint32_t old = 0u;
         if (do_add && !sat) old = atomicAdd(slot, 1u);
         const uint32_t add_rank = sat ? FS_SLOT_CNT_SAT + 1u : (old & FS_SLOT_CNT_MASK) + 1u;
