@@ -518,14 +518,21 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #if FS_FIM_ABLATE >= 3
             mask = 0ull;
 #endif
+            // (the prefetch is issued unconditionally — past the end of the mask it re-reads chunk 0 and the values are never
+            // used: no branch, no zeroing of three registers per iteration)
+            auto fetch = [&](int c, float &x, float &y, float &z) {
+                const int cc = (c >= 0 && FS_BOUND(c < a.n_chunks, 3)) ? c : 0;
+                const uint32_t l = (uint32_t)(cc * 64 + lane);
+                x = ldg32(LX, l); y = ldg32(LY, l); z = ldg32(LZ, l);
+            };
             int c0 = pop(), c1 = pop();
-            float x0 = 0.f, y0 = 0.f, z0 = 0.f, x1 = 0.f, y1 = 0.f, z1 = 0.f;
-            if (c0 >= 0 && FS_BOUND(c0 < a.n_chunks, 3)) { const uint32_t l = (uint32_t)(c0 * 64 + lane); x0 = ldg32(LX, l); y0 = ldg32(LY, l); z0 = ldg32(LZ, l); }
-            if (c1 >= 0 && FS_BOUND(c1 < a.n_chunks, 3)) { const uint32_t l = (uint32_t)(c1 * 64 + lane); x1 = ldg32(LX, l); y1 = ldg32(LY, l); z1 = ldg32(LZ, l); }
+            float x0, y0, z0, x1, y1, z1;
+            fetch(c0, x0, y0, z0);
+            fetch(c1, x1, y1, z1);
             while (c0 >= 0) {
                 const int c2 = pop();
-                float x2 = 0.f, y2 = 0.f, z2 = 0.f;
-                if (c2 >= 0 && FS_BOUND(c2 < a.n_chunks, 3)) { const uint32_t l = (uint32_t)(c2 * 64 + lane); x2 = ldg32(LX, l); y2 = ldg32(LY, l); z2 = ldg32(LZ, l); }
+                float x2, y2, z2;
+                fetch(c2, x2, y2, z2);
                 // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
                 const float dx = x0 - t[0], dy = y0 - t[1], dz = z0 - t[2];
                 const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
