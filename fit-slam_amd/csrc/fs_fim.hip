@@ -525,16 +525,10 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const uint32_t l = (uint32_t)(cc * 64 + lane);
                 x = ldg32(LX, l); y = ldg32(LY, l); z = ldg32(LZ, l);
             };
-            int c0 = pop(), c1 = pop();
-            float x0, y0, z0, x1, y1, z1;
-            fetch(c0, x0, y0, z0);
-            fetch(c1, x1, y1, z1);
-            while (c0 >= 0) {
-                const int c2 = pop();
-                float x2, y2, z2;
-                fetch(c2, x2, y2, z2);
+            // One chunk's landmarks in registers: test, compact, and score whenever 64 are queued.
+            auto body = [&](float wx, float wy, float wz) {
                 // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
-                const float dx = x0 - t[0], dy = y0 - t[1], dz = z0 - t[2];
+                const float dx = wx - t[0], dy = wy - t[1], dz = wz - t[2];
                 const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
                 const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
                 const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
@@ -566,8 +560,20 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                         if (__any(overflow)) raise_overflow();
                     }
                 }
-                c0 = c1; x0 = x1; y0 = y1; z0 = z1;
-                c1 = c2; x1 = x2; y1 = y2; z1 = z2;
+            };
+            // Two register sets take turns (the loop is unrolled by two): while one chunk is tested the next one's landmarks
+            // arrive in the other set — no register rotation.
+            float xa, ya, za, xb, yb, zb;
+            int ca = pop();
+            fetch(ca, xa, ya, za);
+            while (ca >= 0) {
+                const int cb = pop();
+                fetch(cb, xb, yb, zb);
+                body(xa, ya, za);
+                if (cb < 0) break;
+                ca = pop();
+                fetch(ca, xa, ya, za);
+                body(xb, yb, zb);
             }
         }
         FS_STAMP(2);
