@@ -534,11 +534,13 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
                 const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
                 bool vis = (n2 <= a.maxd2);
-                if (CONE1 || a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px * px >= a.cos2 * n2);
-                else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px * px <= a.cos2 * n2));
+                float px2 = px * px;
+                asm("" : "+v"(px2));      // (keeps the compiler from pairing this product with cos2 * n2 in a v_pk_mul_f32 that needs two moves)
+                if (CONE1 || a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px2 >= a.cos2 * n2);
+                else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px2 <= a.cos2 * n2));
                 if (n_parts > 1) vis = vis && voxel_part(a, vis, px, n_parts) == part;   // wave-uniform branch
                 // ---- 3. compact
-                const unsigned long long m = __ballot(vis);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(vis);     // (the mask itself; __ballot goes through an integer compare)
                 if (m != 0ull) {
                     if (vis) {
                         const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
