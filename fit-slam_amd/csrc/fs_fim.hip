@@ -195,7 +195,14 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
         const bool has_match = xmin <= FS_SLOT_CNT_MASK;
         const uint32_t jm = x0 == xmin ? 0u : (x1 == xmin ? 1u : (x2 == xmin ? 2u : 3u));
         // slots fill in order: the first empty one is the number of occupied ones
-        const uint32_t used = (w0 < 1u ? w0 : 1u) + (w1 < 1u ? w1 : 1u) + (w2 < 1u ? w2 : 1u) + (w3 < 1u ? w3 : 1u);   // v_min_u32 x 4
+        // (v_min_u32 by hand: the compiler turns min(w, 1) back into a compare / add-with-carry chain through VCC, whose
+        // write-then-read hazards it pads with s_nop)
+        uint32_t u0, u1, u2, u3;
+        asm("v_min_u32 %0, 1, %1" : "=v"(u0) : "v"(w0));
+        asm("v_min_u32 %0, 1, %1" : "=v"(u1) : "v"(w1));
+        asm("v_min_u32 %0, 1, %1" : "=v"(u2) : "v"(w2));
+        asm("v_min_u32 %0, 1, %1" : "=v"(u3) : "v"(w3));
+        const uint32_t used = (u0 + u1) + (u2 + u3);
         const bool can_insert = !has_match && used < 4u;
         uint32_t *slot = table + (hb << 2) + (has_match ? jm : (used < 4u ? used : 0u));
         uint32_t prev = 0xffffffffu;
