@@ -628,14 +628,17 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // cross-wave sums in fp64, one thread per quantity; the 6x6 assembly and log det run in
         // fs_fim_finish_kernel so that this kernel carries no private arrays
         const bool failed = __builtin_amdgcn_readfirstlane(sh_overflow[buf]) != 0;
-        if (tid < FS_NACC && !failed) {
+        // (the sums by the first lanes of wave 1, the flags and counters below by thread 0: the two halves of the epilogue run side
+        // by side instead of one after the other on wave 0, which everybody waits for at the next barrier)
+        const int qi = tid - (WAVES > 1 ? 64 : 0);
+        if (qi >= 0 && qi < FS_NACC && !failed) {
             float part[WAVES];
 #pragma unroll
-            for (int w = 0; w < WAVES; ++w) part[w] = sh_red[tid * WAVES + w];
+            for (int w = 0; w < WAVES; ++w) part[w] = sh_red[qi * WAVES + w];
             double x = 0.0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) x += (double)part[w];
-            if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + tid] = x;
+            if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + qi] = x;
         }
         if (tid == 0) {
             a.overflow[c] = failed ? fail_code : 0u;                  // the HBM tier re-scores flagged candidates
