@@ -11,7 +11,6 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB = os.path.join(CSRC, "libfitslam_frontier.so")
 SOURCES = ["fs_raymarch.hip", "fs_fim.hip", "fs_rank.hip", "fs_sort.hip", "fs_gridops.hip", "fs_frontier.hip", "fs_keyframes.hip", "fs_capi.hip"]
 HEADERS = ["fs_internal.h", os.path.join("..", "..", "include", "fitslam_frontier.h")]
 
@@ -19,33 +18,44 @@ HEADERS = ["fs_internal.h", os.path.join("..", "..", "include", "fitslam_frontie
 # the specification; fused multiply-adds appear only where the code calls fma explicitly.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
-RESOURCES = os.path.join(CSRC, "kernel_resources.json")
 # The FIM workers run two 512-thread (or one 1024-thread) workgroups per CU = 4 waves per SIMD: more than 128 VGPRs
 # halves the occupancy, and a spill lands in the innermost loop.  The register allocation of these kernels has flipped
 # on innocent-looking edits, so the build checks it.
 RESOURCE_LIMITS = {"fs_fim_kernel": (128, 0)}
-if os.environ.get("FS_BOUNDS"):           # development: range-checked global accesses in the FIM (counter 30) and ray (29) kernels
-    HIPCC_FLAGS += ["-DFS_FIM_BOUNDS", "-DFS_RAY_BOUNDS"]
+
+# ---- development builds.  Every knob below switches on code behind `#ifdef FS_DEV` (cycle stamps, the schedule recorder,
+# range checks) or changes a tuning constant.  A build with any of them NEVER overwrites the production library: it goes to
+# libfitslam_frontier_dev<hash of the flags>.so with objects of its own, and a process only loads it while the same
+# environment variables are set — so a half-finished experiment cannot leave a doctored library behind for tests or bench.
+DEV_FLAGS = []
+if os.environ.get("FS_BOUNDS"):           # range-checked global accesses in the FIM (counter 30) and ray (29) kernels
+    DEV_FLAGS += ["-DFS_FIM_BOUNDS", "-DFS_RAY_BOUNDS"]
     RESOURCE_LIMITS = {}                  # (the checks cost registers: a few bytes of scratch are fine in this build)
-if os.environ.get("FS_FIM_ABLATE"):       # development: timing-only ablations of the FIM worker (wrong results; see fs_fim.hip)
-    HIPCC_FLAGS.append("-DFS_FIM_ABLATE=" + os.environ["FS_FIM_ABLATE"])
-if os.environ.get("FS_T1_WAVES_PER_EU"):  # development: occupancy target of the FIM worker's register allocation
-    HIPCC_FLAGS.append("-DFS_T1_WAVES_PER_EU=" + os.environ["FS_T1_WAVES_PER_EU"])
+if os.environ.get("FS_T1_WAVES_PER_EU"):  # occupancy target of the FIM worker's register allocation
+    DEV_FLAGS.append("-DFS_T1_WAVES_PER_EU=" + os.environ["FS_T1_WAVES_PER_EU"])
     RESOURCE_LIMITS = {}
-if os.environ.get("FS_T1_THREADS"):       # development: workgroup size of the FIM worker (default 512)
-    HIPCC_FLAGS.append("-DFS_T1_THREADS=" + os.environ["FS_T1_THREADS"])
-if os.environ.get("FS_FIM_STAMPS"):       # development: per-phase cycle counters of the FIM worker in counters 16..24
-    HIPCC_FLAGS.append("-DFS_FIM_STAMPS")
-    if os.environ.get("FS_FIM_STAMPS") == "wave":   # ... and the barrier wait / scoring time by wave index (tools/fim_stamps.py prints them)
-        HIPCC_FLAGS.append("-DFS_FIM_STAMPS_PER_WAVE")
-if os.environ.get("FS_RAY_UNROLL"):       # development: speculative cell loads in flight per lane of the ray walks (default 4; 8: -1 %, 2: +4 % on C3)
-    HIPCC_FLAGS.append("-DFS_RAY_UNROLL=" + os.environ["FS_RAY_UNROLL"])
-if os.environ.get("FS_RAY_WAVES"):        # development: fans (waves) per workgroup of the ray-march kernel (default 4)
-    HIPCC_FLAGS.append("-DFS_RAY_WAVES=" + os.environ["FS_RAY_WAVES"])
-if os.environ.get("FS_RAY_ABLATE"):       # development, timing only: ray kernels without the walk (set-up + epilogue: 0.056 of 0.232 ms on C3)
-    HIPCC_FLAGS.append("-DFS_RAY_ABLATE")
-if os.environ.get("FS_FIM_SCHEDULE"):     # development: per-candidate start / duration / workgroup of the persistent FIM grid (tools/fim_schedule.py)
-    HIPCC_FLAGS.append("-DFS_FIM_SCHEDULE")
+if os.environ.get("FS_T1_THREADS"):       # workgroup size of the FIM worker (default 512)
+    DEV_FLAGS.append("-DFS_T1_THREADS=" + os.environ["FS_T1_THREADS"])
+if os.environ.get("FS_FIM_STAMPS"):       # per-phase cycle counters of the FIM worker in counters 16..26 (tools/fim_stamps.py)
+    DEV_FLAGS.append("-DFS_FIM_STAMPS")
+    if os.environ.get("FS_FIM_STAMPS") == "wave":   # ... and the barrier wait / scoring time by wave index
+        DEV_FLAGS.append("-DFS_FIM_STAMPS_PER_WAVE")
+if os.environ.get("FS_RAY_UNROLL"):       # speculative cell loads in flight per lane of the ray walks (default 4)
+    DEV_FLAGS.append("-DFS_RAY_UNROLL=" + os.environ["FS_RAY_UNROLL"])
+if os.environ.get("FS_RAY_WAVES"):        # fans (waves) per workgroup of the ray-march kernel (default 4)
+    DEV_FLAGS.append("-DFS_RAY_WAVES=" + os.environ["FS_RAY_WAVES"])
+if os.environ.get("FS_FIM_SCHEDULE"):     # per-candidate start / duration / workgroup of the persistent FIM grid (tools/fim_schedule.py)
+    DEV_FLAGS.append("-DFS_FIM_SCHEDULE")
+if os.environ.get("FS_EXTRA_FLAGS"):      # anything else an experiment wants to define (A/B variants inside the sources)
+    DEV_FLAGS += os.environ["FS_EXTRA_FLAGS"].split()
+    RESOURCE_LIMITS = {} if os.environ.get("FS_NO_LIMITS") else RESOURCE_LIMITS
+SUFFIX = ""
+if DEV_FLAGS:
+    import hashlib
+    SUFFIX = "_dev" + hashlib.sha1(" ".join(DEV_FLAGS).encode()).hexdigest()[:8]
+    HIPCC_FLAGS = HIPCC_FLAGS + ["-DFS_DEV"] + DEV_FLAGS
+LIB = os.path.join(CSRC, f"libfitslam_frontier{SUFFIX}.so")
+RESOURCES = os.path.join(CSRC, f"kernel_resources{SUFFIX}.json")
 
 
 def hipcc() -> str:
@@ -105,7 +115,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cc = hipcc()
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, src.replace(".hip", SUFFIX + ".o"))
         src_path = os.path.join(CSRC, src)
         hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src_path), hdr_t):
