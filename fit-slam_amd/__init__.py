@@ -8,6 +8,6 @@ binding), synth.py (synthetic workloads), shard.py (multi-GPU sharding) and host
 reference interface).  It never imports oracle/.
 """
 from . import _build, capi, synth  # noqa: F401
-from .capi import FrontierScorer, FsError, RECORD_DTYPE, load_library  # noqa: F401
+from .capi import FrontierScorer, FsError, MultiScorer, RECORD_DTYPE, load_library  # noqa: F401
 
-__all__ = ["FrontierScorer", "FsError", "RECORD_DTYPE", "load_library", "capi", "synth", "_build"]
+__all__ = ["FrontierScorer", "MultiScorer", "FsError", "RECORD_DTYPE", "load_library", "capi", "synth", "_build"]

@@ -27,6 +27,9 @@ EXPORTED_SYMBOLS = [
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim", "fs_information_frontier_pair",
     "fs_upload_keyframes", "fs_information_for_pose",
     "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_selftest_fp64",
+    "fs_multi_create", "fs_multi_destroy", "fs_multi_num_devices", "fs_multi_ctx", "fs_multi_last_error", "fs_multi_shard_bounds",
+    "fs_multi_set_option", "fs_multi_set_ray_params", "fs_multi_upload_grid", "fs_multi_upload_landmarks", "fs_multi_lookup_generate",
+    "fs_multi_lookup_load", "fs_multi_set_fim_params", "fs_multi_max_arrival", "fs_multi_score_candidates",
 ]
 
 RECORD_DTYPE = np.dtype([("arrival", "<i4"), ("argmax", "<i4"), ("yaw", "<f4"), ("info_ref", "<f4"),
@@ -120,9 +123,27 @@ def load_library(build: bool = True):
     L.fs_score_candidates_dev.argtypes = [vp, i32] + [vp] * 5
     L.fs_rank_candidates.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp]
     L.fs_selftest_fp64.argtypes = [vp, i32, C.POINTER(i64)]
+    L.fs_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.fs_multi_destroy.argtypes = [vp]
+    L.fs_multi_destroy.restype = None
+    L.fs_multi_num_devices.argtypes = [vp]
+    L.fs_multi_ctx.argtypes = [vp, C.c_int]
+    L.fs_multi_ctx.restype = vp
+    L.fs_multi_last_error.argtypes = [vp]
+    L.fs_multi_last_error.restype = C.c_char_p
+    L.fs_multi_shard_bounds.argtypes = [i32, C.c_int, C.c_int, C.POINTER(i32), C.POINTER(i32)]
+    L.fs_multi_set_option.argtypes = [vp, C.c_char_p, dbl]
+    L.fs_multi_set_ray_params.argtypes = [vp, C.POINTER(RayParamsC)]
+    L.fs_multi_upload_grid.argtypes = [vp, vp, i32, i32, i32, C.POINTER(dbl * 3), dbl]
+    L.fs_multi_upload_landmarks.argtypes = [vp, vp, i32]
+    L.fs_multi_lookup_generate.argtypes = [vp, vp]
+    L.fs_multi_lookup_load.argtypes = [vp, C.c_char_p]
+    L.fs_multi_set_fim_params.argtypes = [vp, C.POINTER(FimParamsC)]
+    L.fs_multi_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
+    L.fs_multi_score_candidates.argtypes = [vp, i32] + [vp] * 5
     for name in EXPORTED_SYMBOLS:
         f = getattr(L, name)
-        if name not in ("fs_ctx_destroy", "fs_last_error"):
+        if name not in ("fs_ctx_destroy", "fs_last_error", "fs_multi_destroy", "fs_multi_last_error", "fs_multi_ctx"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -191,15 +212,7 @@ class FrontierScorer:
     def set_ray_params(self, max_camera_depth=2.0, delta_theta=0.10, camera_fov=1.04, robot_radius=0.60,
                        n_rays=0, elev=(0.0,), obst=(240, 254), trace=(255, 255), factor_max=1.2,
                        factor_min=0.70, polygon=(-1e300, -1e300, 1e300, 1e300)):
-        p = RayParamsC()
-        p.max_camera_depth, p.delta_theta, p.camera_fov, p.robot_radius = max_camera_depth, delta_theta, camera_fov, robot_radius
-        p.n_rays, p.n_elev = int(n_rays), len(elev)
-        for i, e in enumerate(elev[:FS_MAX_ELEV]):
-            p.elev[i] = float(e)
-        p.obst_min, p.obst_max, p.trace_min, p.trace_max = int(obst[0]), int(obst[1]), int(trace[0]), int(trace[1])
-        p.factor_max, p.factor_min = factor_max, factor_min
-        for i in range(4):
-            p.polygon[i] = float(polygon[i])
+        p = _ray_params_c(max_camera_depth, delta_theta, camera_fov, robot_radius, n_rays, elev, obst, trace, factor_max, factor_min, polygon)
         self._check(self._L.fs_set_ray_params(self._h, C.byref(p)))
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         self._check(self._L.fs_ray_fan_shape(self._h, C.byref(a), C.byref(b), C.byref(c)))
@@ -378,6 +391,103 @@ class FrontierScorer:
         bad = C.c_int64()
         self._check(self._L.fs_selftest_fp64(self._h, int(max_abs), C.byref(bad)))
         return bad.value
+
+
+def _ray_params_c(max_camera_depth=2.0, delta_theta=0.10, camera_fov=1.04, robot_radius=0.60, n_rays=0, elev=(0.0,),
+                  obst=(240, 254), trace=(255, 255), factor_max=1.2, factor_min=0.70, polygon=(-1e300, -1e300, 1e300, 1e300)):
+    p = RayParamsC()
+    p.max_camera_depth, p.delta_theta, p.camera_fov, p.robot_radius = max_camera_depth, delta_theta, camera_fov, robot_radius
+    p.n_rays, p.n_elev = int(n_rays), len(elev)
+    for i, e in enumerate(elev[:FS_MAX_ELEV]):
+        p.elev[i] = float(e)
+    p.obst_min, p.obst_max, p.trace_min, p.trace_max = int(obst[0]), int(obst[1]), int(trace[0]), int(trace[1])
+    p.factor_max, p.factor_min = factor_max, factor_min
+    for i in range(4):
+        p.polygon[i] = float(polygon[i])
+    return p
+
+
+def shard_bounds(n: int, n_shards: int, shard: int):
+    """fs_multi_shard_bounds: the block of `shard` — the partition rule of the multi-device scorer (needs no GPU)."""
+    L = load_library()
+    lo, hi = C.c_int32(), C.c_int32()
+    rc = L.fs_multi_shard_bounds(int(n), int(n_shards), int(shard), C.byref(lo), C.byref(hi))
+    if rc != FS_OK:
+        raise FsError(rc, "fs_multi_shard_bounds: bad arguments")
+    return lo.value, hi.value
+
+
+class MultiScorer:
+    """fs_multi: ONE process and ONE calling thread over several GPUs (or several contexts on one: repeat the ordinal).
+    Staging calls are broadcast; score_candidates cuts the list into contiguous blocks, runs them side by side and returns
+    the records in list order."""
+
+    def __init__(self, devices=(0,)):
+        self._L = load_library()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._L.fs_multi_create(ids, len(devices), C.byref(h))
+        if rc != FS_OK:
+            raise FsError(rc, "fs_multi_create failed: no gfx950 device under one of the ordinals (no CPU fallback exists)")
+        self._h = h
+        self.n_devices = len(devices)
+
+    def _check(self, rc):
+        if rc != FS_OK:
+            raise FsError(rc, (self._L.fs_multi_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fs_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self._check(self._L.fs_multi_set_option(self._h, key.encode(), float(value)))
+
+    def set_ray_params(self, **kw):
+        p = _ray_params_c(**kw)
+        self._check(self._L.fs_multi_set_ray_params(self._h, C.byref(p)))
+
+    def upload_grid(self, cells, origin, resolution):
+        c = np.ascontiguousarray(cells, dtype=np.uint8)
+        if c.ndim == 2:
+            c = c[None]
+        nz, ny, nx = c.shape
+        o = (C.c_double * 3)(*[float(v) for v in origin])
+        self._check(self._L.fs_multi_upload_grid(self._h, _p(c), nx, ny, nz, C.byref(o), float(resolution)))
+
+    def upload_landmarks(self, xyz):
+        lm = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        self._check(self._L.fs_multi_upload_landmarks(self._h, _p(lm), lm.shape[0]))
+
+    def lookup_generate(self, bounds=None):
+        b = None if bounds is None else np.ascontiguousarray(bounds, dtype=np.float32)
+        self._check(self._L.fs_multi_lookup_generate(self._h, _p(b)))
+
+    def set_fim_params(self, max_dist=14.0, max_angle=1.0):
+        p = FimParamsC(max_dist, max_angle)
+        self._check(self._L.fs_multi_set_fim_params(self._h, C.byref(p)))
+
+    def max_arrival(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._L.fs_multi_max_arrival(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(max_value=a.value, max_gt=b.value, min_gt=c.value)
+
+    def score_candidates(self, goal_xyz, frontier_size=None, blacklisted=None, achievable_in=None) -> np.ndarray:
+        goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+        n = goal.shape[0]
+        fs = None if frontier_size is None else np.ascontiguousarray(frontier_size, dtype=np.int32)
+        bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+        ai = None if achievable_in is None else np.ascontiguousarray(achievable_in, dtype=np.uint8)
+        rec = np.zeros(n, dtype=RECORD_DTYPE)
+        self._check(self._L.fs_multi_score_candidates(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(rec)))
+        return rec
 
 
 def record_status(rec):

@@ -1504,12 +1504,15 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     return FS_OK;
 }
 
-int fs_score_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
-                        const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records)
+// fs_score_candidates in two halves, so that one host thread can keep several devices busy (fs_multi.hip): `begin` stages
+// the candidate columns, launches the kernels and requests the records into the context's page-locked buffer — everything
+// asynchronous on the context's stream; `end` waits for that stream and hands the records over.
+int fs_score_candidates_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                              const uint8_t *blacklisted, const uint8_t *achievable_in)
 {
     if (!c) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    if (n < 0 || (n > 0 && (!goal_xyz || !records))) return fail(c, FS_E_INVALID, "null pointer");
+    if (n < 0 || (n > 0 && !goal_xyz)) return fail(c, FS_E_INVALID, "null pointer");
     if (n == 0) return FS_OK;
     int rc = check_scoring_state(c, true, true);
     if (rc) return rc;
@@ -1521,9 +1524,28 @@ int fs_score_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int3
     if (rc) return rc;
     FS_HIP(c, c->h_out.ensure(sizeof(fs_record) * (size_t)n));
     FS_HIP(c, hipMemcpyAsync(c->h_out.p, c->d_records.p, sizeof(fs_record) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    return FS_OK;
+}
+
+int fs_score_candidates_end(fs_ctx *c, int32_t n, fs_record *records)
+{
+    if (!c) return FS_E_INVALID;
+    if (n < 0 || (n > 0 && !records)) return fail(c, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    FS_HIP(c, hipSetDevice(c->device));
     FS_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(records, c->h_out.p, sizeof(fs_record) * (size_t)n);
     return FS_OK;
+}
+
+int fs_score_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                        const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records)
+{
+    if (!c) return FS_E_INVALID;
+    if (n < 0 || (n > 0 && (!goal_xyz || !records))) return fail(c, FS_E_INVALID, "null pointer");
+    const int rc = fs_score_candidates_begin(c, n, goal_xyz, frontier_size, blacklisted, achievable_in);
+    if (rc) return rc;
+    return fs_score_candidates_end(c, n, records);
 }
 
 // ------------------------------------------------------------------ utility + ranking

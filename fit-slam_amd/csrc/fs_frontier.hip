@@ -9,8 +9,8 @@
 //   component of F around it (:119-143) — so the search finds exactly the 8-connected components of F that touch E.
 // Both connectivity problems are solved with a lock-free union-find over the cell array (roots = smallest cell index
 // of a component: a canonical label), three passes over the grid each, instead of a serial queue.  The start cell is
-// nearestFreeCell's (DEP/src/Helpers.cpp:285-329) — an exact single-lane emulation of its queue, which ends at once in
-// the normal case of a robot standing on a free cell.  What is NOT reproduced is order-dependent by construction in the
+// nearestFreeCell's (DEP/src/Helpers.cpp:285-329) — an exact emulation of its queue, bounded to the ring in which it ends
+// (found by a map-wide reduction) and free in the normal case of a robot standing on a free cell.  What is NOT reproduced is order-dependent by construction in the
 // reference: cutting a component into pieces of max_frontier_cluster_size + 1 cells in queue order (:146-178) and the
 // angular-median goal point of each piece (:158-170); the number and sizes of the pieces follow from a component's
 // size, and are reported as such (fs_frontier_cluster::size).
@@ -48,7 +48,9 @@ struct FcArgs {
     double reach;               // max_frontier_distance + max_frontier_cluster_size * resolution * 1.414 (:67)
     int32_t lethal_threshold;
     int32_t *parent_t, *parent_f, *aux;
-    int32_t *state;             // [8]: 0 start cell, 1..4 roots of the start cell's expanded neighbours (-1: none), 5 clusters found, 6 cells found
+    int32_t *state;             // [8]: 0 start cell, 1..4 roots of the start cell's expanded neighbours (-1: none), 5 clusters found, 6 cells found,
+                                //      7 Chebyshev distance from the robot's cell to the nearest cell below the lethal threshold (INT_MAX: none)
+    int32_t pos;                // the robot's cell
 };
 
 // per cell: is it expandable (T) / a frontier cell (F)?  parent arrays start as singletons (or -1 outside the set)
@@ -79,6 +81,7 @@ __global__ void fs_fc_classify_kernel(const FcArgs a)
     a.parent_t[i] = t ? i : -1;
     a.parent_f[i] = f ? i : -1;
     a.aux[i] = -1;
+    if (i == 0) a.state[7] = 0x7fffffff;                                    // (reduced by the next kernel)
 }
 
 // forward neighbours only (each pair once): right, down (4-connected T); + down-left, down-right (8-connected F)
@@ -88,6 +91,13 @@ __global__ void fs_fc_union_kernel(const FcArgs a)
     if (i >= a.nx * a.ny) return;
     const int y = i / a.nx, x = i - y * a.nx;
     const bool right = x < a.nx - 1, down = y < a.ny - 1, left = x > 0;
+    // how far nearestFreeCell will have to look: its search is an unobstructed 8-connected flood from the robot's cell, i.e. it
+    // reaches cells in rings of growing Chebyshev distance and stops in the first ring that holds a cell below the threshold
+    if ((int)a.map[i] < (a.lethal_threshold & 0xff)) {
+        const int py = a.pos / a.nx, px = a.pos - py * a.nx;
+        const int d = max(abs(x - px), abs(y - py));
+        if (d < a.state[7]) atomicMin(&a.state[7], d);
+    }
     if (a.parent_t[i] >= 0) {
         if (right && a.parent_t[i + 1] >= 0) uf_union(a.parent_t, i, i + 1);
         if (down && a.parent_t[i + a.nx] >= 0) uf_union(a.parent_t, i, i + a.nx);
@@ -108,36 +118,47 @@ __global__ void fs_fc_flatten_kernel(const FcArgs a)
     if (a.parent_f[i] >= 0) a.parent_f[i] = uf_find(a.parent_f, i);
 }
 
-// One lane: the start cell of the outer search (:44-54) and the components of T its neighbours expand into.
-// nearestFreeCell is emulated with its own queue (in `queue`, visited flags in `visited`): first cell in queue order
-// with cost < (unsigned char)lethal_threshold.
-__global__ void fs_fc_start_kernel(const FcArgs a, int32_t pos, uint32_t *queue, uint8_t *visited)
+// One wave: the start cell of the outer search (:44-54) and the components of T its neighbours expand into.
+// nearestFreeCell (DEP/src/Helpers.cpp:285-329) returns the first cell IN THE ORDER OF ITS QUEUE whose cost is below
+// (unsigned char)lethal_threshold; the queue order is emulated exactly, by one lane — but only inside the box the search can
+// reach before it ends: state[7] (reduced over the whole map by the kernels before) is the ring in which it ends, so the
+// emulation touches at most (2 d + 3)^2 cells, the wave clears just that box of the visited flags, a robot on a free cell
+// (d = 0, the normal case) costs nothing, and a map without any such cell (the reference walks its whole queue and gives
+// up, :51-54) is answered at once.
+__global__ void fs_fc_start_kernel(const FcArgs a, uint32_t *queue, uint8_t *visited)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const int n = a.nx * a.ny;
+    if (blockIdx.x != 0) return;
+    const int pos = a.pos;
     const int val = a.lethal_threshold & 0xff;                              // the parameter is an unsigned char (Helpers.hpp:141)
+    const int ring = a.state[7];
     int start = pos;
-    if (!(a.map[pos] < val)) {
-        uint32_t head = 0, tail = 0;
-        queue[tail++] = (uint32_t)pos;
-        visited[pos] = 1;
-        bool found = false;
-        while (head < tail) {
-            const int idx = (int)queue[head++];
-            if (a.map[idx] < val) { start = idx; found = true; break; }
-            const int y = idx / a.nx, x = idx - y * a.nx;
-            const bool l = x > 0, r = x < a.nx - 1, u = y > 0, d = y < a.ny - 1;
-            // nhood8's order (Helpers.cpp:199-252): -1, +1, -nx, +nx, -1-nx, -1+nx, +1-nx, +1+nx
-            const int nb[8] = {l ? idx - 1 : -1, r ? idx + 1 : -1, u ? idx - a.nx : -1, d ? idx + a.nx : -1,
-                               (l && u) ? idx - 1 - a.nx : -1, (l && d) ? idx - 1 + a.nx : -1,
-                               (r && u) ? idx + 1 - a.nx : -1, (r && d) ? idx + 1 + a.nx : -1};
-            for (int k = 0; k < 8; ++k) {
-                const int j = nb[k];
-                if (j >= 0 && j < n && !visited[j]) { queue[tail++] = (uint32_t)j; visited[j] = 1; }
+    if (ring != 0x7fffffff && ring > 0) {
+        const int py = pos / a.nx, px = pos - py * a.nx;
+        const int x0 = max(0, px - ring - 1), x1 = min(a.nx - 1, px + ring + 1), y0 = max(0, py - ring - 1), y1 = min(a.ny - 1, py + ring + 1);
+        const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+        for (int t = threadIdx.x; t < w * h; t += blockDim.x) visited[(y0 + t / w) * a.nx + x0 + t % w] = 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t head = 0, tail = 0;
+            queue[tail++] = (uint32_t)pos;
+            visited[pos] = 1;
+            while (head < tail) {
+                const int idx = (int)queue[head++];
+                if (a.map[idx] < val) { start = idx; break; }
+                const int y = idx / a.nx, x = idx - y * a.nx;
+                const bool l = x > x0, r = x < x1, u = y > y0, d = y < y1;  // (cells beyond the box are never dequeued before the search ends)
+                // nhood8's order (Helpers.cpp:199-252): -1, +1, -nx, +nx, -1-nx, -1+nx, +1-nx, +1+nx
+                const int nb[8] = {l ? idx - 1 : -1, r ? idx + 1 : -1, u ? idx - a.nx : -1, d ? idx + a.nx : -1,
+                                   (l && u) ? idx - 1 - a.nx : -1, (l && d) ? idx - 1 + a.nx : -1,
+                                   (r && u) ? idx + 1 - a.nx : -1, (r && d) ? idx + 1 + a.nx : -1};
+                for (int k = 0; k < 8; ++k) {
+                    const int j = nb[k];
+                    if (j >= 0 && !visited[j]) { queue[tail++] = (uint32_t)j; visited[j] = 1; }
+                }
             }
         }
-        if (!found) start = pos;                                            // :51-54
     }
+    if (threadIdx.x != 0) return;
     a.state[0] = start;
     const int y = start / a.nx, x = start - y * a.nx;
     const int nb[4] = {x > 0 ? start - 1 : -1, x < a.nx - 1 ? start + 1 : -1, y > 0 ? start - a.nx : -1, y < a.ny - 1 ? start + a.nx : -1};
@@ -223,15 +244,13 @@ hipError_t fs_launch_frontier_clusters(const uint8_t *d_map, int nx, int ny, dou
                                        int32_t *d_aux, uint32_t *d_queue, uint8_t *d_visited, int32_t *d_state, int32_t *d_labels,
                                        int32_t max_clusters, fs_frontier_cluster *d_clusters, long long *d_sums, hipStream_t s)
 {
-    FcArgs a{d_map, nx, ny, ox, oy, res, px, py, reach, lethal_threshold, d_parent_t, d_parent_f, d_aux, d_state};
+    FcArgs a{d_map, nx, ny, ox, oy, res, px, py, reach, lethal_threshold, d_parent_t, d_parent_f, d_aux, d_state, start_pos};
     const int n = nx * ny;
     const dim3 grid((n + 255) / 256), block(256);
     hipLaunchKernelGGL(fs_fc_classify_kernel, grid, block, 0, s, a);
     hipLaunchKernelGGL(fs_fc_union_kernel, grid, block, 0, s, a);
     hipLaunchKernelGGL(fs_fc_flatten_kernel, grid, block, 0, s, a);
-    hipError_t e = hipMemsetAsync(d_visited, 0, (size_t)n, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fs_fc_start_kernel, dim3(1), dim3(64), 0, s, a, start_pos, d_queue, d_visited);
+    hipLaunchKernelGGL(fs_fc_start_kernel, dim3(1), dim3(256), 0, s, a, d_queue, d_visited);
     hipLaunchKernelGGL(fs_fc_seed_kernel, grid, block, 0, s, a);
     hipLaunchKernelGGL(fs_fc_enumerate_kernel, grid, block, 0, s, a, max_clusters, d_clusters, d_sums);
     hipLaunchKernelGGL(fs_fc_collect_kernel, grid, block, 0, s, a, d_labels, d_clusters, d_sums);

@@ -201,4 +201,9 @@ hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hipStream_t s);
 
+// fs_score_candidates split for the multi-device scorer (fs_capi.hip): launch everything / wait and copy out
+extern "C" int fs_score_candidates_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                                         const uint8_t *blacklisted, const uint8_t *achievable_in);
+extern "C" int fs_score_candidates_end(fs_ctx *c, int32_t n, fs_record *records);
+
 #endif

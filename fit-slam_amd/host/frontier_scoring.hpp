@@ -22,6 +22,7 @@
 #ifndef FITSLAM_FRONTIER_SCORING_HPP_
 #define FITSLAM_FRONTIER_SCORING_HPP_
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <functional>
@@ -30,6 +31,7 @@
 #include <memory>
 #include <mutex>
 #include <optional>
+#include <queue>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -446,74 +448,340 @@ inline std::vector<bool> isConnectable(ScoringContext &ctx, const Costmap2D &cos
     return out;
 }
 
-// DEP/include/.../FrontierSearch.hpp:31-127 — the producer of the candidate list.  searchFrom's two nested breadth-first
-// searches become ONE fs_frontier_clusters call; what comes back is the 8-connected component structure the reference's
-// queues walk (same cells, same clusters).  The reference then cuts a cluster into pieces of max_frontier_cluster_size + 1
-// cells in queue order and takes an angular median as each piece's goal (FrontierSearch.cpp:146-205): steps that depend
-// on the order of its queue by construction, left to the caller on the cell lists returned here.
+// DEP/include/.../Frontier.hpp:151-161
+inline size_t generateUID(const FrontierPtr &output)
+{
+    std::hash<double> hash_fn;
+    return hash_fn(output->getGoalPoint().x) ^ (hash_fn(output->getGoalPoint().y) << 1);
+}
+
+// DEP/include/.../FrontierSearch.hpp:31-127 — the producer of the candidate list, same signature:
+//     std::vector<FrontierPtr> FrontierSearch::searchFrom(geometry_msgs::msg::Point position)   (FrontierSearch.cpp:21)
+// What searchFrom computes splits into a part that does not depend on the order of its queues and one that does:
+//   * which cells are frontier cells, which 8-connected components of them the search reaches, their sizes — ONE
+//     fs_frontier_clusters call on the GPU (stencil + union-find labelling; bit-exact against the reference's search);
+//   * per component, the reference's own tail on the host (buildNewFrontier, :98-216): a breadth-first walk from the
+//     component's seed cell in nhood8 order that cuts the component into pieces of max_frontier_cluster_size + 1 cells
+//     in the order of its queue, and per piece the angular-median goal point (getCentroidOfCells, SortByMedianFunctor,
+//     std::sort, middle element) and setSize.  That tail is inherently serial and tiny (it touches frontier cells only).
+// The seed of a component and the order of the output list follow from the order of the reference's OUTER search:
+//   SeedOrder::Reference  the outer breadth-first search is replayed on the host (map cells < 254 inside the search
+//                         radius, nhood4 order, nearestFreeCell start) only to learn in which order, and at which cell, it
+//                         meets the components — output identical to the reference's, record for record;
+//   SeedOrder::Nearest    (default) no outer search: components in ascending label order, seed = the component's cell
+//                         nearest the robot (ties: smaller index).  Same components, same number and sizes of records; a
+//                         goal point may be a different cell of its piece than the reference's queue order would pick.
 class FrontierSearch
 {
 public:
+    enum class SeedOrder { Nearest, Reference };
     struct Cluster
     {
         int label = -1, size = 0;                       // label: smallest cell index of the component
         Point centroid;                                 // mean of the cell centres (mapToWorld)
-        std::vector<std::pair<double, double>> cells;   // cell centres, ascending cell index (frontier_cell_indices' content)
     };
     FrontierSearch(std::shared_ptr<ScoringContext> ctx, std::shared_ptr<Costmap2D> costmap, int min_frontier_cluster_size = 1,
-                   int max_frontier_cluster_size = 20, double max_frontier_distance = 50.0, int lethal_threshold = 160)
+                   int max_frontier_cluster_size = 20, double max_frontier_distance = 50.0, int lethal_threshold = 160,
+                   SeedOrder seed_order = SeedOrder::Nearest)
         : ctx_(std::move(ctx)), costmap_(std::move(costmap)), min_frontier_cluster_size_(min_frontier_cluster_size),
           max_frontier_cluster_size_(max_frontier_cluster_size), max_frontier_distance_(max_frontier_distance),
-          original_search_distance_(max_frontier_distance), lethal_threshold_(lethal_threshold) {}
+          original_search_distance_(max_frontier_distance), lethal_threshold_(lethal_threshold), seed_order_(seed_order) {}
     void reset() { every_frontier_list.clear(); }
     void incrementSearchDistance(double value) { max_frontier_distance_ += value; }
     void resetSearchDistance() { max_frontier_distance_ = original_search_distance_; }
     std::vector<std::vector<double>> getAllFrontiers() { return every_frontier_list; }
+    void setSeedOrder(SeedOrder o) { seed_order_ = o; }
+    const std::vector<Cluster> &lastClusters() const { return clusters_; }   // the GPU stage's output of the last search
 
-    // FrontierSearch.cpp:21-96 up to the clusters; the grid must have been staged (FrontierCostCalculator::updateCostmap)
-    std::vector<Cluster> searchFrom(Point position)
+    // FrontierSearch.cpp:21-96.  The grid must have been staged (FrontierCostCalculator::updateCostmap).
+    std::vector<FrontierPtr> searchFrom(Point position)
     {
+        std::vector<FrontierPtr> frontier_list;
+        clusters_.clear();
+        unsigned int mx, my;
+        if (!costmap_->worldToMap(position.x, position.y, mx, my)) return frontier_list;     // :26-33
         const unsigned int nx = costmap_->getSizeInCellsX(), ny = costmap_->getSizeInCellsY();
-        std::vector<int32_t> labels((size_t)nx * ny);
+        labels_.assign((size_t)nx * ny, -1);
         std::vector<fs_frontier_cluster> raw((size_t)nx * ny / 2 + 1);
         int32_t n = 0;
         int64_t n_cells = 0;
         const double xy[2] = {position.x, position.y};
         ctx_->check(fs_frontier_clusters(ctx_->get(), xy, lethal_threshold_, max_frontier_distance_, max_frontier_cluster_size_,
-                                         labels.data(), (int32_t)raw.size(), raw.data(), &n, &n_cells), "fs_frontier_clusters");
-        std::vector<Cluster> out((size_t)n);
-        std::unordered_map<int, size_t> slot;
+                                         labels_.data(), (int32_t)raw.size(), raw.data(), &n, &n_cells), "fs_frontier_clusters");
+        clusters_.resize((size_t)n);
         for (int32_t k = 0; k < n; ++k) {
-            out[k].label = raw[k].label; out[k].size = raw[k].size;
-            out[k].centroid.x = raw[k].centroid_x; out[k].centroid.y = raw[k].centroid_y;
-            slot[raw[k].label] = (size_t)k;
+            clusters_[k].label = raw[k].label; clusters_[k].size = raw[k].size;
+            clusters_[k].centroid.x = raw[k].centroid_x; clusters_[k].centroid.y = raw[k].centroid_y;
         }
-        for (unsigned int idx = 0; idx < nx * ny; ++idx) {
-            if (labels[idx] < 0) continue;
-            unsigned int mx, my;
-            double wx, wy;
-            costmap_->indexToCells(idx, mx, my);
-            costmap_->mapToWorld(mx, my, wx, wy);
-            out[slot[labels[idx]]].cells.emplace_back(wx, wy);
-            every_frontier_list.push_back({wx, wy});
+        claimed_.assign((size_t)nx * ny, 0);
+        const unsigned int pos = costmap_->getIndex(mx, my);
+        if (seed_order_ == SeedOrder::Reference) {
+            replayOuterSearch(position, pos, frontier_list);
+        } else {
+            // one pass over the labels: the cell of every component nearest the robot's cell
+            std::unordered_map<int, std::pair<long long, unsigned int>> best;
+            for (unsigned int idx = 0; idx < nx * ny; ++idx) {
+                const int l = labels_[idx];
+                if (l < 0) continue;
+                const long long dx = (long long)(idx % nx) - (long long)mx, dy = (long long)(idx / nx) - (long long)my;
+                const long long d2 = dx * dx + dy * dy;
+                auto it = best.find(l);
+                if (it == best.end() || d2 < it->second.first) best[l] = {d2, idx};
+            }
+            for (const Cluster &c : clusters_) emitComponent(best[c.label].second, frontier_list);
         }
-        return out;
-    }
-    // sizes of the Frontier records buildNewFrontier emits for a cluster of n cells (FrontierSearch.cpp:146-205, :81)
-    std::vector<int> pieceSizes(int n) const
-    {
-        std::vector<int> out(n / (max_frontier_cluster_size_ + 1), max_frontier_cluster_size_ + 1);
-        if (n % (max_frontier_cluster_size_ + 1) > min_frontier_cluster_size_) out.push_back(n % (max_frontier_cluster_size_ + 1));
-        return out;
+        return frontier_list;
     }
 
 private:
+    // the neighbourhoods in the order the reference's helpers produce them (DEP/src/Helpers.cpp:185-255): left, right, up,
+    // down; then the four diagonals (-1-sx, -1+sx, +1-sx, +1+sx)
+    int neighbours(unsigned int idx, bool eight, unsigned int out[8]) const
+    {
+        const unsigned int sx = costmap_->getSizeInCellsX(), sy = costmap_->getSizeInCellsY();
+        if (idx > sx * sy - 1) return 0;
+        const bool l = idx % sx > 0, r = idx % sx < sx - 1, u = idx >= sx, d = idx < sx * (sy - 1);
+        int k = 0;
+        if (l) out[k++] = idx - 1;
+        if (r) out[k++] = idx + 1;
+        if (u) out[k++] = idx - sx;
+        if (d) out[k++] = idx + sx;
+        if (eight) {
+            if (l && u) out[k++] = idx - 1 - sx;
+            if (l && d) out[k++] = idx - 1 + sx;
+            if (r && u) out[k++] = idx + 1 - sx;
+            if (r && d) out[k++] = idx + 1 + sx;
+        }
+        return k;
+    }
+    bool unclaimedFrontierCell(unsigned int idx) const { return labels_[idx] >= 0 && !claimed_[idx]; }   // isNewFrontierCell given the GPU's labels
+    std::pair<double, double> cellCentre(unsigned int idx) const
+    {
+        unsigned int cx, cy;
+        double wx, wy;
+        costmap_->indexToCells(idx, cx, cy);
+        costmap_->mapToWorld(cx, cy, wx, wy);
+        return {wx, wy};
+    }
+
+    // FrontierSearch.hpp:84-127: mean of the cells, pushed sideways by 2 sqrt2 cells when some cell lies within three cells of
+    // it (so that the angular order below is taken about a point off the cluster's spine)
+    std::pair<double, double> centroidOfCells(const std::vector<std::pair<double, double>> &cells, double offset) const
+    {
+        double sx = 0, sy = 0;
+        for (const auto &c : cells) { sx += c.first; sy += c.second; }
+        double cx = sx / cells.size(), cy = sy / cells.size();
+        bool near_spine = false;
+        double spread_x = 0, spread_y = 0;
+        for (const auto &c : cells) {
+            if (std::sqrt(std::pow(c.first - cx, 2) + std::pow(c.second - cy, 2)) < costmap_->getResolution() * 3) near_spine = true;
+            spread_x += std::abs(c.first - cx);
+            spread_y += std::abs(c.second - cy);
+        }
+        if (spread_x > spread_y && near_spine) cy -= offset;
+        if (spread_x < spread_y && near_spine) cx -= offset;
+        return {cx, cy};
+    }
+
+    // one Frontier record of a finished piece (FrontierSearch.cpp:156-174 / :191-208): goal = the middle element of the cells
+    // sorted by angle about the centroid (SortByMedianFunctor, FrontierSearch.hpp:156-181 — angles in [0, 2 pi), except that a
+    // first-quadrant angle never sorts before a fourth-quadrant one; not a strict weak order, so the result is whatever
+    // std::sort makes of it: the same library call as the reference)
+    FrontierPtr finishPiece(std::vector<std::pair<double, double>> &cells, int size) const
+    {
+        const auto c = centroidOfCells(cells, costmap_->getResolution() * 1.414 * 2);
+        auto angle = [&](const std::pair<double, double> &p) {
+            double a = std::atan2(p.second - c.second, p.first - c.first);
+            return a < 0 ? a + (2 * M_PI) : a;
+        };
+        std::sort(cells.begin(), cells.end(), [&](const std::pair<double, double> &a, const std::pair<double, double> &b) {
+            const double aa = angle(a), ab = angle(b);
+            if (0 <= aa && aa <= M_PI / 2 && 3 * M_PI / 2 <= ab && ab <= 2 * M_PI) return false;
+            if (0 <= ab && ab <= M_PI / 2 && 3 * M_PI / 2 <= aa && aa <= 2 * M_PI) return true;
+            return aa < ab;
+        });
+        const auto goal = cells[static_cast<int>(cells.size() / 2)];
+        auto out = std::make_shared<Frontier>();
+        out->setGoalPoint(goal.first, goal.second);
+        out->setSize(size);
+        out->setUID(generateUID(out));
+        cells.clear();
+        return out;
+    }
+
+    // buildNewFrontier (FrontierSearch.cpp:98-216) over the component of `seed`, then searchFrom's size filter (:81)
+    void emitComponent(unsigned int seed, std::vector<FrontierPtr> &frontier_list)
+    {
+        int count = 1;
+        std::vector<std::pair<double, double>> piece{cellCentre(seed)};
+        every_frontier_list.push_back({piece[0].first, piece[0].second});
+        claimed_[seed] = 1;
+        std::vector<FrontierPtr> made;
+        std::queue<unsigned int> walk;
+        walk.push(seed);
+        unsigned int nb[8];
+        while (!walk.empty()) {
+            const unsigned int idx = walk.front();
+            walk.pop();
+            const int k = neighbours(idx, true, nb);
+            for (int j = 0; j < k; ++j) {
+                if (!unclaimedFrontierCell(nb[j])) continue;
+                claimed_[nb[j]] = 1;
+                const auto w = cellCentre(nb[j]);
+                every_frontier_list.push_back({w.first, w.second});
+                piece.push_back(w);
+                ++count;
+                walk.push(nb[j]);
+                if (count > max_frontier_cluster_size_) {              // a full piece: max + 1 cells
+                    made.push_back(finishPiece(piece, count));
+                    count = 0;
+                }
+            }
+        }
+        if (count > min_frontier_cluster_size_) made.push_back(finishPiece(piece, count));
+        for (auto &f : made)
+            if (f->getSize() > min_frontier_cluster_size_) frontier_list.push_back(f);
+    }
+
+    // nearestFreeCell (DEP/src/Helpers.cpp:285-329; its `unsigned char val` parameter truncates the threshold)
+    bool nearestFreeCell(unsigned int &result, unsigned int start) const
+    {
+        const unsigned int total = costmap_->getSizeInCellsX() * costmap_->getSizeInCellsY();
+        if (start >= total) return false;
+        const unsigned char val = (unsigned char)lethal_threshold_;
+        std::vector<bool> seen(total, false);
+        std::queue<unsigned int> q;
+        q.push(start);
+        seen[start] = true;
+        unsigned int nb[8];
+        while (!q.empty()) {
+            const unsigned int idx = q.front();
+            q.pop();
+            if (costmap_->getCost(idx) < val) { result = idx; return true; }
+            const int k = neighbours(idx, true, nb);
+            for (int j = 0; j < k; ++j)
+                if (!seen[nb[j]]) { seen[nb[j]] = true; q.push(nb[j]); }
+        }
+        return false;
+    }
+
+    // SeedOrder::Reference — the outer search of FrontierSearch.cpp:44-94, replayed for its ORDER only: frontier-cell
+    // membership comes from the GPU's labels
+    void replayOuterSearch(const Point &position, unsigned int pos, std::vector<FrontierPtr> &frontier_list)
+    {
+        const unsigned int total = costmap_->getSizeInCellsX() * costmap_->getSizeInCellsY();
+        std::vector<bool> visited(total, false);
+        std::queue<unsigned int> q;
+        unsigned int clear = 0;
+        q.push(nearestFreeCell(clear, pos) ? clear : pos);
+        visited[q.front()] = true;
+        const double reach = max_frontier_distance_ + (max_frontier_cluster_size_ * costmap_->getResolution() * 1.414);
+        unsigned int nb[8];
+        while (!q.empty()) {
+            const unsigned int idx = q.front();
+            q.pop();
+            const int k = neighbours(idx, false, nb);
+            for (int j = 0; j < k; ++j) {
+                const unsigned int nbr = nb[j];
+                if (costmap_->getCost(nbr) < 254 && !visited[nbr]) {
+                    visited[nbr] = true;
+                    const auto w = cellCentre(nbr);
+                    if (std::sqrt(std::pow(position.x - w.first, 2) + std::pow(position.y - w.second, 2)) < reach) q.push(nbr);
+                } else if (unclaimedFrontierCell(nbr)) {
+                    emitComponent(nbr, frontier_list);
+                }
+            }
+        }
+    }
+
     std::shared_ptr<ScoringContext> ctx_;
     std::shared_ptr<Costmap2D> costmap_;
     int min_frontier_cluster_size_, max_frontier_cluster_size_;
     double max_frontier_distance_, original_search_distance_;
     int lethal_threshold_;
+    SeedOrder seed_order_;
     std::vector<std::vector<double>> every_frontier_list;
+    std::vector<int32_t> labels_;
+    std::vector<uint8_t> claimed_;
+    std::vector<Cluster> clusters_;
+};
+
+// One in-process scorer over several GPUs (fs_multi_* of the C ABI): what ProcessFrontierCostsBT calls from the behaviour-tree
+// thread (DEP/src/ExplorationBT.cpp:376-410) stays ONE object and ONE call on a multi-GPU node.  Staging is broadcast to every
+// device; scoreFrontiers cuts the list into contiguous blocks, runs them side by side and writes the results into the
+// frontiers in list order — arrival information, goal orientation, achievability (CostCalculator.cpp:112-119) and the Fisher
+// information at the pose (goal, best yaw) (isPoseSafe(Point, Point), FisherInfoManager.cpp:31-37).
+class ShardedScorer
+{
+public:
+    explicit ShardedScorer(const std::vector<int> &devices)
+    {
+        const int rc = fs_multi_create(devices.data(), (int)devices.size(), &m_);
+        if (rc != FS_OK) throw std::runtime_error("fs_multi_create failed: no MI355X (gfx950) under one of the device ordinals; there is no CPU fallback");
+    }
+    ~ShardedScorer() { fs_multi_destroy(m_); }
+    ShardedScorer(const ShardedScorer &) = delete;
+    ShardedScorer &operator=(const ShardedScorer &) = delete;
+    fs_multi *get() const { return m_; }
+    int numDevices() const { return fs_multi_num_devices(m_); }
+    void check(int rc, const char *what) const
+    {
+        if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_multi_last_error(m_));
+    }
+    void setRayParams(const fs_ray_params &p) { check(fs_multi_set_ray_params(m_, &p), "fs_multi_set_ray_params"); }
+    // the snapshot point: taken under the costmap's mutex, sent to every device
+    void updateCostmap(Costmap2D &costmap)
+    {
+        std::lock_guard<std::mutex> lock(costmap.getMutex());
+        const double origin[3] = {costmap.getOriginX(), costmap.getOriginY(), costmap.getOriginZ()};
+        check(fs_multi_upload_grid(m_, costmap.getCharMap(), (int32_t)costmap.getSizeInCellsX(), (int32_t)costmap.getSizeInCellsY(),
+                                   (int32_t)costmap.getSizeInCellsZ(), origin, costmap.getResolution()), "fs_multi_upload_grid");
+    }
+    void setLandmarks(const std::vector<float> &xyz) { check(fs_multi_upload_landmarks(m_, xyz.data(), (int32_t)(xyz.size() / 3)), "fs_multi_upload_landmarks"); }
+    void generateLookupTable() { check(fs_multi_lookup_generate(m_, nullptr), "fs_multi_lookup_generate"); }
+    void loadLookupTable(const std::string &path)
+    {
+        if (fs_multi_lookup_load(m_, path.c_str()) != FS_OK) throw std::runtime_error("Cannot load lookup table. Does it exist in the path?");
+    }
+    void setVisibility(double max_dist, double max_angle)
+    {
+        const fs_fim_params p{max_dist, max_angle};
+        check(fs_multi_set_fim_params(m_, &p), "fs_multi_set_fim_params");
+    }
+    double setMaxArrivalInformation()
+    {
+        double max_value = 0, max_gt = 0, min_gt = 0;
+        check(fs_multi_max_arrival(m_, &max_value, &max_gt, &min_gt), "fs_multi_max_arrival");
+        return max_value;
+    }
+    // order-preserving; `blacklisted` (or empty) as in FrontierCostsManager.cpp:77-86
+    std::vector<fs_record> scoreFrontiers(std::vector<FrontierPtr> &frontiers, const std::vector<uint8_t> &blacklisted = {})
+    {
+        const int32_t n = (int32_t)frontiers.size();
+        std::vector<fs_record> rec((size_t)n);
+        if (n == 0) return rec;
+        std::vector<double> goal(3 * (size_t)n);
+        std::vector<int32_t> fsize((size_t)n);
+        std::vector<uint8_t> ach_in((size_t)n);
+        for (int32_t i = 0; i < n; ++i) {
+            const Point &g = frontiers[i]->getGoalPoint();
+            goal[3 * i] = g.x; goal[3 * i + 1] = g.y; goal[3 * i + 2] = g.z;
+            fsize[i] = frontiers[i]->getSize();
+            ach_in[i] = frontiers[i]->isAchievable();
+        }
+        check(fs_multi_score_candidates(m_, n, goal.data(), fsize.data(), blacklisted.empty() ? nullptr : blacklisted.data(),
+                                        ach_in.data(), rec.data()), "fs_multi_score_candidates");
+        for (int32_t i = 0; i < n; ++i) {
+            frontiers[i]->setArrivalInformation((double)rec[i].arrival);
+            frontiers[i]->setGoalOrientation((double)rec[i].yaw);
+            frontiers[i]->setAchievability((rec[i].flags & FS_FLAG_ACHIEVABLE) != 0);
+            frontiers[i]->setFisherInformation((double)rec[i].info_ref);
+        }
+        return rec;
+    }
+
+private:
+    fs_multi *m_ = nullptr;
 };
 
 // DEP/include/.../CostAssigner.hpp:43-59

@@ -1,6 +1,8 @@
 // host_mirror_driver.cpp — exercises the C++ host-side mirror (frontier_scoring.hpp) on the GPU.
 // tests/test_host_mirror.py writes a workload file, runs this program and compares its output with the
 // oracle.  Usage: host_mirror_driver <workload.bin> <result.bin>
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -131,20 +133,70 @@ int main(int argc, char **argv)
         if (connectable.size() != (size_t)n) ++failures;
     }
 
-    // FrontierSearch::searchFrom from the start pose: clusters, their cells and the piece sizes the reference would emit
+    // FrontierSearch::searchFrom from the start pose -> std::vector<FrontierPtr>, in both seed orders; the records of the
+    // reference order are written out for the comparison with the oracle (goal points and sizes, record for record)
     size_t fs_clusters = 0, fs_cells = 0, fs_pieces = 0;
+    std::vector<double> frontier_rows;                 // [k][3]: goal x, goal y, size — SeedOrder::Reference
     {
         FrontierSearch search(ctx, costmap);
         Point robot; robot.x = start[0]; robot.y = start[1];
-        const auto clusters = search.searchFrom(robot);
-        fs_clusters = clusters.size();
-        for (const auto &cl : clusters) {
-            if ((size_t)cl.size != cl.cells.size()) ++failures;
-            fs_cells += cl.cells.size();
-            for (int piece : search.pieceSizes(cl.size)) fs_pieces += (piece > 0);
+        const auto nearest = search.searchFrom(robot);
+        fs_clusters = search.lastClusters().size();
+        fs_cells = search.getAllFrontiers().size();
+        fs_pieces = nearest.size();
+        size_t cells_in_clusters = 0;
+        for (const auto &cl : search.lastClusters()) cells_in_clusters += (size_t)cl.size;
+        if (cells_in_clusters != fs_cells) ++failures;
+        search.reset();
+        search.setSeedOrder(FrontierSearch::SeedOrder::Reference);
+        const auto exact = search.searchFrom(robot);
+        if (exact.size() != nearest.size() || search.getAllFrontiers().size() != fs_cells) ++failures;
+        // the seed rule moves goal points inside their pieces, it never changes how many records of which size there are
+        std::vector<int> sa, sb;
+        for (const auto &fr : nearest) sa.push_back(fr->getSize());
+        for (const auto &fr : exact) sb.push_back(fr->getSize());
+        std::sort(sa.begin(), sa.end()); std::sort(sb.begin(), sb.end());
+        if (sa != sb) ++failures;
+        for (const auto &fr : exact) {
+            frontier_rows.push_back(fr->getGoalPoint().x); frontier_rows.push_back(fr->getGoalPoint().y); frontier_rows.push_back((double)fr->getSize());
+            if (fr->getUID() != generateUID(fr)) ++failures;
         }
-        if (search.getAllFrontiers().size() != fs_cells) ++failures;
-        printf("FrontierSearch: %zu clusters, %zu cells, %zu pieces\n", fs_clusters, fs_cells, fs_pieces);
+        printf("FrontierSearch: %zu clusters, %zu cells, %zu Frontier records\n", fs_clusters, fs_cells, fs_pieces);
+    }
+
+    // ShardedScorer: two scoring contexts on the one GPU of the test box, one call from this one thread — the fused records
+    // of the live (not blacklisted) frontiers must equal the single-context results above
+    {
+        ShardedScorer sharded({0, 0});
+        fs_ray_params rp{};
+        rp.max_camera_depth = 2.0; rp.delta_theta = 0.10; rp.camera_fov = 1.04; rp.robot_radius = 0.60;
+        rp.n_rays = 0; rp.n_elev = 1; rp.elev[0] = 0.0;
+        rp.obst_min = 240; rp.obst_max = 254; rp.trace_min = 255; rp.trace_max = 255;
+        rp.factor_max = 1.2; rp.factor_min = 0.70;
+        const float p32[4] = {(float)poly[0], (float)poly[1], (float)poly[2], (float)poly[3]};   // the polygon travels as Point32
+        for (int i = 0; i < 4; ++i) rp.polygon[i] = (double)p32[i];
+        sharded.setRayParams(rp);
+        sharded.updateCostmap(*costmap);
+        sharded.setLandmarks(lm);
+        sharded.generateLookupTable();
+        sharded.setVisibility(14.0, 1.0);
+        sharded.setMaxArrivalInformation();
+        std::vector<FrontierPtr> copies;
+        for (int32_t i = 0; i < n; ++i) {
+            auto fr = std::make_shared<Frontier>();
+            fr->setUID((size_t)i + 1); fr->setSize(sizes[i]); fr->setGoalPoint(goals[2 * i], goals[2 * i + 1]);
+            copies.push_back(fr);
+        }
+        const auto rec = sharded.scoreFrontiers(copies, black);
+        int bad = 0;
+        for (int32_t i = 0; i < n; ++i) {
+            if (black[i]) { bad += (FS_RECORD_STATUS(rec[i].flags) != FS_STATUS_BLACKLISTED); continue; }
+            bad += (double)rec[i].arrival != res_->frontier_arrival_information[i];
+            bad += (double)rec[i].yaw != (double)(float)res_->frontier_list[i]->getGoalYaw();
+            bad += std::fabs(rec[i].info_ref - info[i]) > 2e-6f * std::max(1.0f, std::fabs(info[i]));
+        }
+        printf("ShardedScorer({0,0}): %d devices, %d mismatches against the single context\n", sharded.numDevices(), bad);
+        if (bad || sharded.numDevices() != 2) ++failures;
     }
 
     // error behaviour of the reference interface
@@ -172,8 +224,9 @@ int main(int argc, char **argv)
                                 res_->frontier_distances[i], (double)info[i], (double)kf_info[i], (double)connectable[i]};
         fwrite(row, sizeof(double), 10, o);
     }
-    const double tail[3] = {(double)fs_clusters, (double)fs_cells, (double)fs_pieces};
-    fwrite(tail, sizeof(double), 3, o);
+    const double tail[4] = {(double)fs_clusters, (double)fs_cells, (double)fs_pieces, (double)(frontier_rows.size() / 3)};
+    fwrite(tail, sizeof(double), 4, o);
+    fwrite(frontier_rows.data(), sizeof(double), frontier_rows.size(), o);
     fclose(o);
     printf("failures: %d\n", failures);
     return failures ? 1 : 0;

@@ -296,6 +296,39 @@ int fs_score_candidates(fs_ctx *ctx, int32_t n, const double *goal_xyz, const in
 int fs_score_candidates_dev(fs_ctx *ctx, int32_t n, const double *d_goal_xyz, const int32_t *d_frontier_size,
                             const uint8_t *d_blacklisted, const uint8_t *d_achievable_in, fs_record *d_records);
 
+/* ---------------------------------------------------------------- one process, several GPUs */
+
+/* The reference scores in-process, from its one behaviour-tree thread (DEP/src/main.cpp:9-24,
+ * DEP/src/ExplorationBT.cpp:376-410: ProcessFrontierCostsBT::onStart -> CostAssigner::getFrontierCosts).  fs_multi keeps that
+ * shape on a multi-GPU node: ONE object, ONE calling thread, no launcher and no second process.  It owns one fs_ctx per
+ * entry of device_ids (an ordinal may repeat: two contexts on one GPU, each with its stream), every staging call is
+ * applied to all of them (the grid, the cloud and the table are replicated: 128 MiB + 1.2 MB + 2.8 MB at 512^3), and
+ * fs_multi_score_candidates cuts the frontier list into contiguous blocks of ceil(n / G) candidates (fs_multi_shard_bounds
+ * — the same rule the multi-process bench uses), starts block g on device g without waiting, then collects the 32-byte
+ * records of all blocks into the caller's buffer in list order.  Candidates are independent, so there is no device-to-device
+ * traffic at all; ranking (fs_rank_candidates on fs_multi_ctx(m, 0)) runs on the gathered records. */
+typedef struct fs_multi fs_multi;
+int  fs_multi_create(const int *device_ids, int n_devices, fs_multi **out);
+void fs_multi_destroy(fs_multi *m);
+int  fs_multi_num_devices(const fs_multi *m);
+fs_ctx *fs_multi_ctx(fs_multi *m, int i);                  /* member context i (options, counters, ranking); owned by m */
+const char *fs_multi_last_error(const fs_multi *m);
+/* block [*lo, *hi) of shard `shard` of `n_shards` over a list of n: lo = min(n, shard * ceil(n / n_shards)), hi = min(n, lo + ceil(n / n_shards)) */
+int  fs_multi_shard_bounds(int32_t n, int n_shards, int shard, int32_t *lo, int32_t *hi);
+/* each of these applies the fs_* call of the same name to every member (first failure is returned) */
+int  fs_multi_set_option(fs_multi *m, const char *key, double value);
+int  fs_multi_set_ray_params(fs_multi *m, const fs_ray_params *p);
+int  fs_multi_upload_grid(fs_multi *m, const uint8_t *cells, int32_t nx, int32_t ny, int32_t nz, const double origin_xyz[3], double resolution);
+int  fs_multi_upload_landmarks(fs_multi *m, const float *xyz, int32_t n_landmarks);
+int  fs_multi_lookup_generate(fs_multi *m, const float bounds[6]);
+int  fs_multi_lookup_load(fs_multi *m, const char *path);
+int  fs_multi_set_fim_params(fs_multi *m, const fs_fim_params *p);
+/* setMaxArrivalInformation once (member 0), the limits handed to every member */
+int  fs_multi_max_arrival(fs_multi *m, double *max_value, double *max_gt, double *min_gt);
+/* fs_score_candidates over all members: host buffers in, records [n] out, list order; returns when every block is in */
+int  fs_multi_score_candidates(fs_multi *m, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                               const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records);
+
 /* ---------------------------------------------------------------- utility + ranking */
 
 /* Replaces the U1 block of FrontierCostsManager::assignCosts (DEP/src/FrontierCostsManager.cpp:118,126-205)
