@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_selftest_fp64",
     "fs_multi_create", "fs_multi_destroy", "fs_multi_num_devices", "fs_multi_ctx", "fs_multi_last_error", "fs_multi_shard_bounds",
     "fs_multi_set_option", "fs_multi_set_ray_params", "fs_multi_upload_grid", "fs_multi_upload_landmarks", "fs_multi_lookup_generate",
-    "fs_multi_lookup_load", "fs_multi_set_fim_params", "fs_multi_max_arrival", "fs_multi_score_candidates",
+    "fs_multi_lookup_load", "fs_multi_set_fim_params", "fs_multi_max_arrival", "fs_multi_score_arrival", "fs_multi_score_candidates",
 ]
 
 RECORD_DTYPE = np.dtype([("arrival", "<i4"), ("argmax", "<i4"), ("yaw", "<f4"), ("info_ref", "<f4"),
@@ -140,6 +140,7 @@ def load_library(build: bool = True):
     L.fs_multi_lookup_load.argtypes = [vp, C.c_char_p]
     L.fs_multi_set_fim_params.argtypes = [vp, C.POINTER(FimParamsC)]
     L.fs_multi_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
+    L.fs_multi_score_arrival.argtypes = [vp, i32] + [vp] * 10
     L.fs_multi_score_candidates.argtypes = [vp, i32] + [vp] * 5
     for name in EXPORTED_SYMBOLS:
         f = getattr(L, name)
@@ -478,6 +479,20 @@ class MultiScorer:
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self._check(self._L.fs_multi_max_arrival(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return dict(max_value=a.value, max_gt=b.value, min_gt=c.value)
+
+    def score_arrival(self, goal_xyz, frontier_size=None, blacklisted=None, achievable_in=None, n_rays_total=0):
+        """n_rays_total = n_elev * n_yaw to get the per-ray counts back (0: not requested)."""
+        goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+        n = goal.shape[0]
+        fs = None if frontier_size is None else np.ascontiguousarray(frontier_size, dtype=np.int32)
+        bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+        ai = None if achievable_in is None else np.ascontiguousarray(achievable_in, dtype=np.uint8)
+        rc_arr = np.zeros((n, n_rays_total), dtype=np.int32) if n_rays_total else None
+        arrival = np.zeros(n, dtype=np.int32); argmax = np.zeros(n, dtype=np.int32)
+        yaw = np.zeros(n, dtype=np.float64); ach = np.zeros(n, dtype=np.uint8); status = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_multi_score_arrival(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(rc_arr),
+                                                   _p(arrival), _p(argmax), _p(yaw), _p(ach), _p(status)))
+        return dict(ray_counts=rc_arr, arrival=arrival, argmax=argmax, yaw=yaw, achievable=ach, status=status)
 
     def score_candidates(self, goal_xyz, frontier_size=None, blacklisted=None, achievable_in=None) -> np.ndarray:
         goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)

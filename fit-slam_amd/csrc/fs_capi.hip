@@ -965,10 +965,12 @@ static int upload_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const
     return FS_OK;
 }
 
-int fs_score_arrival(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
-                     const uint8_t *blacklisted, const uint8_t *achievable_in,
-                     int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
-                     uint8_t *achievable, int32_t *status)
+// fs_score_arrival in two halves (see fs_score_candidates_begin / _end): everything up to the copies into the caller's
+// buffers is issued here ...
+int fs_score_arrival_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                           const uint8_t *blacklisted, const uint8_t *achievable_in,
+                           int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
+                           uint8_t *achievable, int32_t *status)
 {
     if (!c) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
@@ -1004,8 +1006,26 @@ int fs_score_arrival(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t
     FS_HIP(c, hipMemcpyAsync(status, c->d_status.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipMemcpyAsync(yaw, c->d_yaw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipMemcpyAsync(achievable, c->d_ach.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    return FS_OK;
+}
+
+// ... and waited for here
+int fs_score_arrival_end(fs_ctx *c)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
     FS_HIP(c, hipStreamSynchronize(c->stream));
     return FS_OK;
+}
+
+int fs_score_arrival(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                     const uint8_t *blacklisted, const uint8_t *achievable_in,
+                     int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
+                     uint8_t *achievable, int32_t *status)
+{
+    const int rc = fs_score_arrival_begin(c, n, goal_xyz, frontier_size, blacklisted, achievable_in, ray_counts, arrival, argmax, yaw, achievable, status);
+    if (rc || n == 0) return rc;
+    return fs_score_arrival_end(c);
 }
 
 int fs_trace_segments(fs_ctx *c, int32_t n, const double *start_xyz, const double *end_xyz, double max_length_cells,

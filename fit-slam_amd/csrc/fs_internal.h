@@ -6,6 +6,18 @@
 #include <stdint.h>
 
 #include "../../include/fitslam_frontier.h"
+#include "../../include/fitslam_frontier_dev.h"
+
+// Instrumentation paths (cycle stamps, schedule recorder, range checks, ablations) exist in FS_DEV builds only — the
+// builds fit-slam_amd/_build.py makes under a library name of their own when one of its FS_* knobs is set.
+#ifndef FS_DEV
+#undef FS_FIM_STAMPS
+#undef FS_FIM_STAMPS_PER_WAVE
+#undef FS_FIM_SCHEDULE
+#undef FS_FIM_BOUNDS
+#undef FS_RAY_BOUNDS
+#undef FS_RAY_ABLATE
+#endif
 
 // ---- ray-march kernel arguments ---------------------------------------------------------------
 // The occupancy grid lives in HBM twice: `cells` is the dense row-major image [nz][ny][nx] the uploads write (and the
@@ -205,5 +217,9 @@ hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hi
 extern "C" int fs_score_candidates_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
                                          const uint8_t *blacklisted, const uint8_t *achievable_in);
 extern "C" int fs_score_candidates_end(fs_ctx *c, int32_t n, fs_record *records);
+extern "C" int fs_score_arrival_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                                      const uint8_t *blacklisted, const uint8_t *achievable_in, int32_t *ray_counts, int32_t *arrival,
+                                      int32_t *argmax, double *yaw, uint8_t *achievable, int32_t *status);
+extern "C" int fs_score_arrival_end(fs_ctx *c);
 
 #endif

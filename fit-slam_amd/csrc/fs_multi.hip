@@ -156,6 +156,39 @@ int fs_multi_max_arrival(fs_multi *m, double *max_value, double *max_gt, double 
     return FS_OK;
 }
 
+int fs_multi_score_arrival(fs_multi *m, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                           const uint8_t *blacklisted, const uint8_t *achievable_in,
+                           int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
+                           uint8_t *achievable, int32_t *status)
+{
+    if (!m || m->ctx.empty()) return FS_E_INVALID;
+    if (n < 0 || (n > 0 && (!goal_xyz || !arrival || !argmax || !yaw || !achievable || !status))) return multi_fail(m, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    const int G = (int)m->ctx.size();
+    int32_t ny = 0, ne = 0;
+    if (ray_counts && fs_ray_fan_shape(m->ctx[0], &ny, &ne, nullptr) != FS_OK) return multi_fail(m, FS_E_STATE, "fs_set_ray_params has not been called");
+    const size_t per = (size_t)ny * (size_t)ne;
+    int first_error = FS_OK, launched = 0;
+    for (int g = 0; g < G; ++g) {
+        int32_t l = 0, h = 0;
+        fs_multi_shard_bounds(n, G, g, &l, &h);
+        const int rc = fs_score_arrival_begin(m->ctx[(size_t)g], h - l, goal_xyz + 3 * (size_t)l, frontier_size ? frontier_size + l : nullptr,
+                                              blacklisted ? blacklisted + l : nullptr, achievable_in ? achievable_in + l : nullptr,
+                                              ray_counts ? ray_counts + per * (size_t)l : nullptr, arrival + l, argmax + l, yaw + l, achievable + l, status + l);
+        if (rc != FS_OK) {
+            first_error = multi_fail(m, rc, "block %d (candidates %d..%d, device %d): %s", g, l, h, m->device[(size_t)g], fs_last_error(m->ctx[(size_t)g]));
+            break;
+        }
+        ++launched;
+    }
+    for (int g = 0; g < launched; ++g) {
+        const int rc = fs_score_arrival_end(m->ctx[(size_t)g]);
+        if (rc != FS_OK && first_error == FS_OK)
+            first_error = multi_fail(m, rc, "block %d (device %d): %s", g, m->device[(size_t)g], fs_last_error(m->ctx[(size_t)g]));
+    }
+    return first_error;
+}
+
 int fs_multi_score_candidates(fs_multi *m, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
                               const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records)
 {

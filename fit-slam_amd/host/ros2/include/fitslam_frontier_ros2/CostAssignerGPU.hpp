@@ -1,8 +1,9 @@
 // CostAssignerGPU.hpp — drop-in for frontier_exploration::CostAssigner
 // (DEP/include/frontier_exploration/CostAssigner.hpp:61-100) whose per-frontier scoring loop
 // (FrontierCostsManager::assignCosts, DEP/src/FrontierCostsManager.cpp:47-213) runs on an MI355X through the C ABI of
-// include/fitslam_frontier.h: ONE fs_score_arrival call for the whole frontier list, the reference's own planner per
-// frontier (roadmap A*, out of the accelerated path), ONE fs_rank_candidates call for the U1 utilities and costs.
+// include/fitslam_frontier.h: ONE fs_multi_score_arrival call for the whole frontier list — cut into one block per GPU of
+// the node's parameter `fitslam_frontier.gpu_devices` (default [0]) inside this one process —, the reference's own planner
+// per frontier (roadmap A*, out of the accelerated path), ONE fs_rank_candidates call for the U1 utilities and costs.
 //
 // Same constructor argument, same public methods, same GetFrontierCostsRequest / GetFrontierCostsResponse (the
 // reference's own structs, not copies): ProcessFrontierCosts (DEP/src/ExplorationBT.cpp:376-441) only needs the type of
@@ -36,7 +37,8 @@ class CostAssignerGPU
 {
 public:
     // DEP/src/CostAssigner.cpp:9-20 + DEP/src/FrontierCostsManager.cpp:6-23 + DEP/src/CostCalculator.cpp:5-21
-    explicit CostAssignerGPU(std::shared_ptr<nav2_costmap_2d::Costmap2DROS> explore_costmap_ros, int device_id = 0);
+    // device_ids: HIP ordinals to score on; empty = the node's parameter `fitslam_frontier.gpu_devices` (default [0])
+    explicit CostAssignerGPU(std::shared_ptr<nav2_costmap_2d::Costmap2DROS> explore_costmap_ros, std::vector<int> device_ids = {});
     ~CostAssignerGPU();
     CostAssignerGPU(const CostAssignerGPU &) = delete;
     CostAssignerGPU &operator=(const CostAssignerGPU &) = delete;
@@ -60,9 +62,10 @@ private:
     bool assignCosts(std::vector<FrontierPtr> &frontier_list, geometry_msgs::msg::Pose start_pose_w);
     void snapshotCostmap();                                  // fs_upload_grid under the costmap mutex
     void pushRayParams();                                    // fs_set_ray_params (+ cached arrival limits)
-    void check(int rc, const char *what) const;              // FS_E_* -> std::runtime_error with fs_last_error
+    void restoreArrivalLimits();                             // hands the cached limits back to every device
+    void check(int rc, const char *what) const;              // FS_E_* -> std::runtime_error with fs_multi_last_error
 
-    fs_ctx *ctx_ = nullptr;
+    fs_multi *scorer_ = nullptr;                             // one fs_ctx per GPU, one calling thread (the BT tick thread)
     nav2_costmap_2d::LayeredCostmap *layered_costmap_ = nullptr;
     nav2_costmap_2d::Costmap2D *costmap_ = nullptr;
     std::shared_ptr<frontier_exploration::FrontierCostCalculator> planner_;   // planning only; never scores

@@ -5,7 +5,8 @@
 // (FIP/src/fisher_information/FisherInfoManager.cpp:52-77) is replaced by the landmark cloud staged ONCE per SLAM map
 // update from topic `map_data` (slam_msgs/msg/MapData — the message the roadmap already subscribes to,
 // DEP/src/planners/FrontierRoadmap.cpp:28); the camera-frame transform and the visibility predicate the server applied
-// are explicit (14 m, DESIGN.md "Visibility"); the table look-up + crowding discount + sum (:83-100,287-324) run in
+// are explicit — node parameters fisherInformation.max_dist_pose_observation / max_angle_pose_observation, defaulting to the
+// reference's request (14.0 m, 4.0 rad = no cone; FisherInfoManager.cpp:63-64); the table look-up + crowding discount + sum (:83-100,287-324) run in
 // fs_score_fim.  Same lookup-table file, same `information > threshold` decision (:112-114).
 #ifndef FITSLAM_FRONTIER_ROS2_FISHER_INFO_MANAGER_GPU_HPP_
 #define FITSLAM_FRONTIER_ROS2_FISHER_INFO_MANAGER_GPU_HPP_
@@ -66,6 +67,7 @@ private:
     std::thread spin_thread_;
     std::mutex ctx_mutex_;                       // the context is single-caller: map updates vs. BT ticks
     std::atomic<bool> have_landmarks_{false};
+    std::atomic<bool> told_about_exhaustive_{false};
 };
 
 }  // namespace fitslam_frontier_ros2

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <limits>
 #include <stdexcept>
+#include <utility>
 
 #include <slam_msgs/srv/get_map.hpp>
 
@@ -16,7 +17,7 @@ namespace fitslam_frontier_ros2
 using frontier_exploration::GetFrontierCostsRequest;
 using frontier_exploration::GetFrontierCostsResponse;
 
-CostAssignerGPU::CostAssignerGPU(std::shared_ptr<nav2_costmap_2d::Costmap2DROS> explore_costmap_ros, int device_id)
+CostAssignerGPU::CostAssignerGPU(std::shared_ptr<nav2_costmap_2d::Costmap2DROS> explore_costmap_ros, std::vector<int> device_ids)
 {
     layered_costmap_ = explore_costmap_ros->getLayeredCostmap();                 // CostAssigner.cpp:11
     costmap_ = explore_costmap_ros->getCostmap();                                // FrontierCostsManager.cpp:19
@@ -35,20 +36,38 @@ CostAssignerGPU::CostAssignerGPU(std::shared_ptr<nav2_costmap_2d::Costmap2DROS> 
     // the reference's calculator is kept for its planners only (roadmap A* / NavFn / Euclidean: out of the GPU path)
     planner_ = std::make_shared<frontier_exploration::FrontierCostCalculator>(explore_costmap_ros);
 
-    if (fs_ctx_create(device_id, nullptr, &ctx_) != FS_OK)
-        throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) device or HIP runtime; there is no CPU fallback");
+    // One scorer object in this process, whatever the number of GPUs: the node's parameter `fitslam_frontier.gpu_devices`
+    // (an integer array, default [0]) lists the HIP ordinals; the frontier list of a tick is cut into one contiguous block
+    // per entry and the blocks run side by side (fs_multi_*, include/fitslam_frontier.h).
+    if (device_ids.empty()) {
+        auto node = explore_costmap_ros->shared_from_this();
+        std::vector<int64_t> ids{0};
+        if (!node->has_parameter("fitslam_frontier.gpu_devices")) node->declare_parameter("fitslam_frontier.gpu_devices", ids);
+        node->get_parameter("fitslam_frontier.gpu_devices", ids);
+        for (const int64_t d : ids) device_ids.push_back(static_cast<int>(d));
+    }
+    if (fs_multi_create(device_ids.data(), static_cast<int>(device_ids.size()), &scorer_) != FS_OK)
+        throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) under one of fitslam_frontier.gpu_devices; there is no CPU fallback");
     pushRayParams();
-    LOG_INFO("CostAssignerGPU: scoring on HIP device " << device_id);
+    LOG_INFO("CostAssignerGPU: scoring on " << fs_multi_num_devices(scorer_) << " HIP device(s)");
 }
 
 CostAssignerGPU::~CostAssignerGPU()
 {
-    fs_ctx_destroy(ctx_);
+    fs_multi_destroy(scorer_);
 }
 
 void CostAssignerGPU::check(int rc, const char *what) const
 {
-    if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_last_error(ctx_));
+    if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_multi_last_error(scorer_));
+}
+
+void CostAssignerGPU::restoreArrivalLimits()
+{
+    // setMaxArrivalInformation's cache (CostCalculator.cpp:125,185-188) survives new parameters and new snapshots
+    if (!arrival_info_limits_set_) return;
+    for (int g = 0; g < fs_multi_num_devices(scorer_); ++g)
+        fs_set_arrival_limits(fs_multi_ctx(scorer_, g), max_arrival_info_gt_, min_arrival_info_gt_);
 }
 
 void CostAssignerGPU::pushRayParams()
@@ -70,8 +89,8 @@ void CostAssignerGPU::pushRayParams()
         p.polygon[0] = p.polygon[1] = -std::numeric_limits<double>::max();
         p.polygon[2] = p.polygon[3] = std::numeric_limits<double>::max();
     }
-    check(fs_set_ray_params(ctx_, &p), "fs_set_ray_params");
-    if (arrival_info_limits_set_) check(fs_set_arrival_limits(ctx_, max_arrival_info_gt_, min_arrival_info_gt_), "fs_set_arrival_limits");
+    check(fs_multi_set_ray_params(scorer_, &p), "fs_multi_set_ray_params");
+    restoreArrivalLimits();
 }
 
 void CostAssignerGPU::snapshotCostmap()
@@ -80,10 +99,10 @@ void CostAssignerGPU::snapshotCostmap()
     // is the snapshot point and is taken under the costmap's own mutex.
     std::unique_lock<nav2_costmap_2d::Costmap2D::mutex_t> lock(*(costmap_->getMutex()));
     const double origin[3] = {costmap_->getOriginX(), costmap_->getOriginY(), 0.0};
-    check(fs_upload_grid(ctx_, costmap_->getCharMap(), static_cast<int32_t>(costmap_->getSizeInCellsX()),
-                         static_cast<int32_t>(costmap_->getSizeInCellsY()), 1, origin, costmap_->getResolution()),
-          "fs_upload_grid");
-    if (arrival_info_limits_set_) check(fs_set_arrival_limits(ctx_, max_arrival_info_gt_, min_arrival_info_gt_), "fs_set_arrival_limits");
+    check(fs_multi_upload_grid(scorer_, costmap_->getCharMap(), static_cast<int32_t>(costmap_->getSizeInCellsX()),
+                               static_cast<int32_t>(costmap_->getSizeInCellsY()), 1, origin, costmap_->getResolution()),
+          "fs_multi_upload_grid");
+    restoreArrivalLimits();
 }
 
 void CostAssignerGPU::setFrontierBlacklist(std::vector<FrontierPtr> &blacklist)
@@ -94,37 +113,29 @@ void CostAssignerGPU::setFrontierBlacklist(std::vector<FrontierPtr> &blacklist)
 
 bool CostAssignerGPU::updateBoundaryPolygon(geometry_msgs::msg::PolygonStamped &explore_boundary)
 {
-    // CostAssigner.cpp:121-167, statement for statement (the Point32 narrowing included)
-    for (const auto &point32 : explore_boundary.polygon.points) {
-        geometry_msgs::msg::Point32 p = point32;
-        polygon_.points.push_back(p);
-    }
+    // What CostAssigner.cpp:121-167 leaves behind is the bounding box [min x, min y, max x, max y] of the exploration
+    // polygon, taken over its float32 vertices (geometry_msgs/Point32).  An empty polygon means "the whole map": the
+    // reference then uses the corners (origin) and (getSizeInMeters) — a size, not origin + size, for the far corner: a
+    // quirk that decides where rays are clamped (CostCalculator.cpp:47-48), so it is kept.  The vertices accumulate across
+    // calls like the reference's member polygon does.
+    for (const auto &vertex : explore_boundary.polygon.points) polygon_.points.push_back(vertex);
     if (polygon_.points.empty()) {
-        geometry_msgs::msg::Point32 temp;
-        temp.x = layered_costmap_->getCostmap()->getOriginX();
-        temp.y = layered_costmap_->getCostmap()->getOriginY();
-        polygon_.points.push_back(temp);
-        temp.y = layered_costmap_->getCostmap()->getSizeInMetersY();
-        polygon_.points.push_back(temp);
-        temp.x = layered_costmap_->getCostmap()->getSizeInMetersX();
-        polygon_.points.push_back(temp);
-        temp.y = layered_costmap_->getCostmap()->getOriginY();
-        polygon_.points.push_back(temp);
+        const nav2_costmap_2d::Costmap2D *map = layered_costmap_->getCostmap();
+        const float x_lo = static_cast<float>(map->getOriginX()), y_lo = static_cast<float>(map->getOriginY());
+        const float x_hi = static_cast<float>(map->getSizeInMetersX()), y_hi = static_cast<float>(map->getSizeInMetersY());
+        for (const auto &xy : {std::pair<float, float>{x_lo, y_lo}, {x_lo, y_hi}, {x_hi, y_hi}, {x_hi, y_lo}}) {
+            geometry_msgs::msg::Point32 corner;
+            corner.x = xy.first; corner.y = xy.second;
+            polygon_.points.push_back(corner);
+        }
     }
-    double min_x_polygon = std::numeric_limits<double>::infinity();
-    double min_y_polygon = std::numeric_limits<double>::infinity();
-    double max_x_polygon = -std::numeric_limits<double>::infinity();
-    double max_y_polygon = -std::numeric_limits<double>::infinity();
-    for (const auto &point : polygon_.points) {
-        min_x_polygon = std::min(min_x_polygon, (double)point.x);
-        min_y_polygon = std::min(min_y_polygon, (double)point.y);
-        max_x_polygon = std::max(max_x_polygon, (double)point.x);
-        max_y_polygon = std::max(max_y_polygon, (double)point.y);
+    const double inf = std::numeric_limits<double>::infinity();
+    double box[4] = {inf, inf, -inf, -inf};
+    for (const auto &vertex : polygon_.points) {
+        box[0] = std::min(box[0], static_cast<double>(vertex.x)); box[1] = std::min(box[1], static_cast<double>(vertex.y));
+        box[2] = std::max(box[2], static_cast<double>(vertex.x)); box[3] = std::max(box[3], static_cast<double>(vertex.y));
     }
-    polygon_xy_min_max_.push_back(min_x_polygon);
-    polygon_xy_min_max_.push_back(min_y_polygon);
-    polygon_xy_min_max_.push_back(max_x_polygon);
-    polygon_xy_min_max_.push_back(max_y_polygon);
+    polygon_xy_min_max_.insert(polygon_xy_min_max_.end(), box, box + 4);         // (appended, as the reference does: the first four count)
     pushRayParams();                                                             // the clamp box of CostCalculator.cpp:47-48
     return true;
 }
@@ -136,7 +147,7 @@ bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geome
     snapshotCostmap();
     if (!arrival_info_limits_set_) {                                             // :52, CostCalculator.cpp:123-191 (cached)
         double max_value = 0, max_gt = 0, min_gt = 0;
-        check(fs_max_arrival(ctx_, &max_value, &max_gt, &min_gt), "fs_max_arrival");
+        check(fs_multi_max_arrival(scorer_, &max_value, &max_gt, &min_gt), "fs_multi_max_arrival");
         if (max_value != 0.0) {
             arrival_info_limits_set_ = true;
             max_arrival_info_gt_ = max_gt;
@@ -171,8 +182,8 @@ bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geome
             black[i] = frontier_blacklist_.count(f) > 0 ? 1 : 0;                 // :77
         }
     }
-    check(fs_score_arrival(ctx_, n, goal.data(), fsize.data(), black.data(), ach_in.data(), nullptr, arrival.data(),
-                           argmax.data(), yaw.data(), ach.data(), status.data()), "fs_score_arrival");
+    check(fs_multi_score_arrival(scorer_, n, goal.data(), fsize.data(), black.data(), ach_in.data(), nullptr, arrival.data(),
+                                 argmax.data(), yaw.data(), ach.data(), status.data()), "fs_multi_score_arrival");
 
     auto map_data = std::make_shared<slam_msgs::srv::GetMap::Response>();        // CostAssigner.cpp:37 (left empty there too)
     for (int32_t i = 0; i < n; ++i) {
@@ -210,10 +221,11 @@ bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geome
         plen[i] = f->getPathLength();
         phead[i] = (black[i] || !f->isAchievable()) ? 0.0 : f->getPathHeading();
     }
-    const int rc = fs_rank_candidates(ctx_, n, rec.data(), black.data(), plen.data(), phead.data(), alpha_, beta_, max_vx_, max_wx_,
+    fs_ctx *rank_ctx = fs_multi_ctx(scorer_, 0);                                  // the gathered list is ranked on the first device
+    const int rc = fs_rank_candidates(rank_ctx, n, rec.data(), black.data(), plen.data(), phead.data(), alpha_, beta_, max_vx_, max_wx_,
                                       cost.data(), au.data(), du.data(), nullptr);
     if (rc == FS_E_RANGE) throw std::runtime_error("Cost out of bounds");        // :148-149,173-174
-    check(rc, "fs_rank_candidates");
+    if (rc != FS_OK) throw std::runtime_error(std::string("fs_rank_candidates: ") + fs_last_error(rank_ctx));
     for (int32_t i = 0; i < n; ++i) {
         if (black[i]) continue;                                                  // its weighted cost is already max (:84)
         frontier_list[i]->setWeightedCost(cost[i]);                              // :130 / :198
@@ -226,28 +238,25 @@ bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geome
 bool CostAssignerGPU::getFrontierCosts(std::shared_ptr<GetFrontierCostsRequest> requestData,
                                        std::shared_ptr<GetFrontierCostsResponse> resultData)
 {
-    setFrontierBlacklist(requestData->prohibited_frontiers);                     // CostAssigner.cpp:75
-    const bool costsResult = assignCosts(requestData->frontier_list, requestData->start_pose.pose);   // :79 (processOurApproach)
-    if (costsResult == false) {                                                  // :81-85
-        resultData->success = false;
-        return resultData->success;
+    // The contract of CostAssigner.cpp:73-119: the prohibited frontiers join the blacklist first; the request's frontiers are
+    // scored IN PLACE; the response carries the very same pointers in the very same order plus three parallel columns read
+    // back from them (weighted cost, path length in metres, arrival information); a failed scoring (empty list, no polygon)
+    // only clears `success`.
+    setFrontierBlacklist(requestData->prohibited_frontiers);
+    resultData->success = assignCosts(requestData->frontier_list, requestData->start_pose.pose);
+    if (!resultData->success) return false;
+    const std::vector<FrontierPtr> &scored = requestData->frontier_list;
+    resultData->frontier_list.assign(scored.begin(), scored.end());
+    resultData->frontier_costs.resize(scored.size());
+    resultData->frontier_distances.resize(scored.size());
+    resultData->frontier_arrival_information.resize(scored.size());
+    for (size_t i = 0; i < scored.size(); ++i) {
+        resultData->frontier_costs[i] = scored[i]->getWeightedCost();
+        resultData->frontier_distances[i] = scored[i]->getPathLengthInM();
+        resultData->frontier_arrival_information[i] = scored[i]->getArrivalInformation();
     }
-    resultData->success = true;
-    std::vector<FrontierPtr> frontiers_list;
-    std::vector<double> frontier_costs, frontier_distances, frontier_arrival_information;
-    for (auto &frontier : requestData->frontier_list) {                          // :92-99
-        frontiers_list.push_back(frontier);
-        frontier_costs.push_back(frontier->getWeightedCost());
-        frontier_distances.push_back(frontier->getPathLengthInM());
-        frontier_arrival_information.push_back(frontier->getArrivalInformation());
-    }
-    resultData->frontier_list = frontiers_list;
-    resultData->frontier_costs = frontier_costs;
-    resultData->frontier_distances = frontier_distances;
-    resultData->frontier_arrival_information = frontier_arrival_information;
-    if (resultData->frontier_list != requestData->frontier_list)                 // :105-108
-        throw std::runtime_error("Lists are not SAME!");
-    return resultData->success;
+    if (resultData->frontier_list != requestData->frontier_list) throw std::runtime_error("Lists are not SAME!");   // :105-108
+    return true;
 }
 
 }  // namespace fitslam_frontier_ros2

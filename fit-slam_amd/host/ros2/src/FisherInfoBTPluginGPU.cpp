@@ -5,7 +5,8 @@
 //   "EvaluateFisherInformation"  -> FisherInformationBTGPU below: the tick of FisherInfoBTPlugin.cpp:24-57 with
 //                                   FisherInformationManagerGPU::isPoseSafe behind it
 //   "MarkLethalFOV"              -> the reference's own node, untouched: it is actuation (a costmap service call), not on
-//                                   the scoring path, so it is taken from the reference plugin's registration
+//                                   the scoring path; it comes from the reference plugin — already loaded, or registered from
+//                                   here when this plugin is loaded alone (see registerNodes: loading both is fine)
 // Blackboard key "latest_robot_pose", input port `exhaustive_landmark_search`, TF map -> base_footprint, the 700 ms
 // back-off and the error code on FAILURE are the reference's.
 #include "fitslam_frontier_ros2/FisherInfoBTPluginGPU.hpp"
@@ -89,13 +90,19 @@ namespace roadmap_explorer
                                               std::shared_ptr<nav2_costmap_2d::Costmap2DROS> explore_costmap_ros,
                                               std::shared_ptr<tf2_ros::Buffer> tf_buffer)
     {
-        // "MarkLethalFOV" (and the CPU "EvaluateFisherInformation") exactly as the reference registers them; builders
-        // are lazy, so nothing of the CPU manager is constructed by this
-        FisherInfoBTPlugin reference_plugin;
-        reference_plugin.registerNodes(factory, node, explore_costmap_ros, tf_buffer);
-
-        // ... then the GPU node takes over the ID the behaviour tree refers to
-        factory.unregisterBuilder("EvaluateFisherInformation");
+        // This plugin owns ONE node ID, "EvaluateFisherInformation".  "MarkLethalFOV" is the reference's (its class lives in
+        // the reference plugin's .cpp, FisherInfoBTPlugin.cpp:73-197, and can only be registered by that plugin).
+        //   * loaded NEXT TO the reference plugin (list this one after it in the node's bt_plugins): both IDs are there
+        //     already — the reference's CPU builder of "EvaluateFisherInformation" is replaced, nothing is registered twice;
+        //   * loaded INSTEAD of it: the factory knows neither ID yet — the reference's registration runs first (builders are
+        //     lazy: no CPU manager is constructed by it), then the ID is taken over as above.
+        const auto &known = factory.builders();
+        const bool have_evaluate = known.count("EvaluateFisherInformation") > 0, have_mark = known.count("MarkLethalFOV") > 0;
+        if (!have_evaluate && !have_mark) {
+            FisherInfoBTPlugin reference_plugin;
+            reference_plugin.registerNodes(factory, node, explore_costmap_ros, tf_buffer);
+        }
+        if (factory.builders().count("EvaluateFisherInformation") > 0) factory.unregisterBuilder("EvaluateFisherInformation");
         BT::NodeBuilder builder_evaluate =
             [explore_costmap_ros, node, tf_buffer](const std::string &name, const BT::NodeConfiguration &config)
         {

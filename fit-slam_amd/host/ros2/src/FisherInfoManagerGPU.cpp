@@ -20,12 +20,20 @@ FisherInformationManagerGPU::FisherInformationManagerGPU(std::shared_ptr<nav2_ut
 {
     if (fs_ctx_create(device_id, nullptr, &ctx_) != FS_OK)
         throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) device or HIP runtime; there is no CPU fallback");
-    // FisherInfoManager.cpp:63-64: radius 14.0, observation-angle filter disabled in the request (4.0 > pi).  Which
-    // landmarks the un-vendored server returned beyond that is unknown; the scorer's definition is the
-    // 14 m range sphere intersected with a 1.0 rad cone about the camera's +x axis (LoadLookupMain.cpp:115).
+    // Which landmarks a pose "sees" is the reference's REQUEST to the SLAM server (FisherInfoManager.cpp:63-64):
+    // max_dist_pose_observation = 14.0, max_angle_pose_observation = 4.0 — "greater than pi to disregard angle of
+    // observation".  Those two numbers are this manager's defaults, as node parameters of the same names, so that
+    // isPoseSafe's verdicts against the threshold of 550 are taken over the set the reference asks for (a value >= pi
+    // switches the cone off).  What the un-vendored server does beyond the request is unknown; in-tree hints
+    // for a tighter camera model are LoadLookupMain.cpp:115 (1.0 rad about +x) — set max_angle_pose_observation to 1.0 for it.
+    double max_dist = 14.0, max_angle = 4.0;
+    if (!node_->has_parameter("fisherInformation.max_dist_pose_observation")) node_->declare_parameter("fisherInformation.max_dist_pose_observation", max_dist);
+    if (!node_->has_parameter("fisherInformation.max_angle_pose_observation")) node_->declare_parameter("fisherInformation.max_angle_pose_observation", max_angle);
+    node_->get_parameter("fisherInformation.max_dist_pose_observation", max_dist);
+    node_->get_parameter("fisherInformation.max_angle_pose_observation", max_angle);
     fs_fim_params vis;
-    vis.max_dist = 14.0;
-    vis.max_angle = 1.0;
+    vis.max_dist = max_dist;
+    vis.max_angle = max_angle;
     check(fs_set_fim_params(ctx_, &vis), "fs_set_fim_params");
     loadLookupTable();                                                           // :10
 
@@ -134,8 +142,14 @@ bool FisherInformationManagerGPU::poseInformation(const std::vector<geometry_msg
                         nullptr, nullptr, nullptr, nullptr, nullptr) == FS_OK;
 }
 
-bool FisherInformationManagerGPU::isPoseSafe(geometry_msgs::msg::Pose &given_pose, bool /*exhaustiveSearch*/, float &information)
+bool FisherInformationManagerGPU::isPoseSafe(geometry_msgs::msg::Pose &given_pose, bool exhaustiveSearch, float &information)
 {
+    // `exhaustiveSearch` travels in the reference's request (FisherInfoManager.cpp:65) and is acted on by the SLAM server:
+    // false lets it restrict the search to its local map, true makes it go through every map point.  Here the whole
+    // staged cloud is tested against the visibility volume on every call — the exhaustive search IS the only mode, it
+    // costs microseconds — so `true` is honoured as asked and `false` cannot narrow anything: said once, not silently.
+    if (!exhaustiveSearch && !told_about_exhaustive_.exchange(true))
+        LOG_INFO("FisherInformationManagerGPU: exhaustive_search = false has no narrower mode on the GPU path; every staged landmark is tested on every query");
     const double fisher_information_threshold =
         parameterInstance.getValue<double>("fisherInformation.fisher_information_threshold");    // FisherInfoManager.cpp:41
     std::vector<float> info;

@@ -103,32 +103,8 @@ const char *fs_last_error(const fs_ctx *ctx);
 int  fs_abi_version(void);
 int  fs_synchronize(fs_ctx *ctx);
 
-/* Per-kernel device time.  With timing enabled every kernel launch is bracketed by hipEvents on
- * the context's stream; fs_kernel_time returns and resets the accumulated (ms, launches) of
- * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM HBM-table tier, 3 utility/rank, 4 candidate sort,
- * 5 frontier-cell stencil. */
-int  fs_enable_kernel_timing(fs_ctx *ctx, int enable);
-int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
-
-/* Tuning / diagnostic knobs (no reference counterpart).  Keys: "fim.cull" (default 1): per-chunk
- * bounding-sphere culling of the landmark cloud; 0 tests every landmark (brute force; identical results).
- * "ray.sort" (default 1): ray-march candidates in Morton order of their goal cell (lists of >= 2048).
- * "sort.costmap" (default 1): that sort puts the blocks of the map whose candidates were expensive in the previous call
- * first (the persistent FIM grid drains better; identical results); "sort.reverse" (default 0): reversed block order, a
- * knob for measuring how much the order matters.
- * "ray.layout" (default 0): which copy of the grid the ray walks read — 0 picks by ray length (row-major image below
- * 96 cells, 8x8x2-brick copy from there on: the measured winners), 1 / 2 force the row-major / bricked walk, 3 walks an
- * LDS copy of the start cell's neighbourhood where the fan is planar and at most 64 cells deep, 4 the span walk (sixteen
- * lanes take sixteen consecutive steps of one ray; row-major image or its transpose by major axis) for fans of at most
- * 512 rays and 1024 cells, else as 0; 5 the column walk on 3-D grids (z-fastest image, the elevation rings of a yaw in
- * neighbouring lanes) (identical results in every case; DESIGN.md 4.1 holds the measured table).
- * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
- * landmarks scanned, in 32nds, that decides the number of scoring passes: DESIGN.md 4.2). */
-int  fs_set_option(fs_ctx *ctx, const char *key, double value);
-/* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
- * 4 = candidates scored in several voxel-partitioned passes, 5 = candidates re-scored with the table in HBM,
- * 6 = unresolved (always 0). */
-int  fs_get_counter(fs_ctx *ctx, int which, int64_t *value, int reset);
+/* (per-kernel timing, device counters, tuning knobs and the fp64 self test — development and measurement aids that have no
+ * counterpart in the reference — are declared in fitslam_frontier_dev.h) */
 
 /* ---------------------------------------------------------------- arrival information (ray-cast) */
 
@@ -325,6 +301,11 @@ int  fs_multi_lookup_load(fs_multi *m, const char *path);
 int  fs_multi_set_fim_params(fs_multi *m, const fs_fim_params *p);
 /* setMaxArrivalInformation once (member 0), the limits handed to every member */
 int  fs_multi_max_arrival(fs_multi *m, double *max_value, double *max_gt, double *min_gt);
+/* fs_score_arrival over all members (same arguments; every output array in list order) */
+int  fs_multi_score_arrival(fs_multi *m, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
+                            const uint8_t *blacklisted, const uint8_t *achievable_in,
+                            int32_t *ray_counts, int32_t *arrival, int32_t *argmax, double *yaw,
+                            uint8_t *achievable, int32_t *status);
 /* fs_score_candidates over all members: host buffers in, records [n] out, list order; returns when every block is in */
 int  fs_multi_score_candidates(fs_multi *m, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
                                const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records);
@@ -342,13 +323,6 @@ int fs_rank_candidates(fs_ctx *ctx, int32_t n, const fs_record *records, const u
                        double alpha, double beta, double max_vx, double max_wz,
                        double *weighted_cost, double *arrival_utility, double *distance_utility,
                        int32_t *order);
-
-/* ---------------------------------------------------------------- self test */
-
-/* Runs the fp64 primitives the ray set-up relies on (sqrt of exact small integers, division) on the
- * device and compares them with the host's correctly rounded results bit for bit.
- * *mismatches = 0 is required for bit-exact ray geometry. */
-int fs_selftest_fp64(fs_ctx *ctx, int32_t max_abs, int64_t *mismatches);
 
 #ifdef __cplusplus
 }

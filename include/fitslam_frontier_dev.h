@@ -1,0 +1,56 @@
+/*
+ * fitslam_frontier_dev.h — development and measurement entry points of libfitslam_frontier.so.
+ *
+ * Nothing here replaces a reference interface: these calls exist for bench.py (per-kernel device time, the M_tested counter of
+ * the roofline figure), for the test-suite (the fp64 self test, forcing a code path) and for experiments.  A drop-in user of
+ * the scoring path needs fitslam_frontier.h only.  Builds with instrumentation compiled in (per-phase cycle stamps, the
+ * schedule recorder, range-checked accesses) are a separate matter: they are made by fit-slam_amd/_build.py when one of
+ * its FS_* environment knobs is set, carry -DFS_DEV, and go to a library file of their own.
+ */
+#ifndef FITSLAM_FRONTIER_DEV_H_
+#define FITSLAM_FRONTIER_DEV_H_
+
+#include "fitslam_frontier.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Per-kernel device time.  With timing enabled every kernel launch is bracketed by hipEvents on
+ * the context's stream; fs_kernel_time returns and resets the accumulated (ms, launches) of
+ * kernel kind: 0 ray-march, 1 FIM accumulate, 2 FIM HBM-table tier, 3 utility/rank, 4 candidate sort,
+ * 5 frontier-cell stencil. */
+int  fs_enable_kernel_timing(fs_ctx *ctx, int enable);
+int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
+
+/* Tuning / diagnostic knobs (no reference counterpart).  Keys: "fim.cull" (default 1): per-chunk
+ * bounding-sphere culling of the landmark cloud; 0 tests every landmark (brute force; identical results).
+ * "ray.sort" (default 1): ray-march candidates in Morton order of their goal cell (lists of >= 2048).
+ * "sort.costmap" (default 1): that sort puts the blocks of the map whose candidates were expensive in the previous call
+ * first (the persistent FIM grid drains better; identical results); "sort.reverse" (default 0): reversed block order, a
+ * knob for measuring how much the order matters.
+ * "ray.layout" (default 0): which copy of the grid the ray walks read — 0 picks by ray length (row-major image below
+ * 96 cells, 8x8x2-brick copy from there on: the measured winners), 1 / 2 force the row-major / bricked walk, 3 walks an
+ * LDS copy of the start cell's neighbourhood where the fan is planar and at most 64 cells deep, 4 the span walk (sixteen
+ * lanes take sixteen consecutive steps of one ray; row-major image or its transpose by major axis) for fans of at most
+ * 512 rays and 1024 cells, else as 0; 5 the column walk on 3-D grids (z-fastest image, the elevation rings of a yaw in
+ * neighbouring lanes) (identical results in every case; DESIGN.md 4.1 holds the measured table).
+ * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
+ * landmarks scanned, in 32nds, that decides the number of scoring passes: DESIGN.md 4.2). */
+int  fs_set_option(fs_ctx *ctx, const char *key, double value);
+/* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
+ * 4 = candidates scored in several voxel-partitioned passes, 5 = candidates re-scored with the table in HBM,
+ * 6 = unresolved (always 0). */
+int  fs_get_counter(fs_ctx *ctx, int which, int64_t *value, int reset);
+
+/* ---------------------------------------------------------------- self test */
+
+/* Runs the fp64 primitives the ray set-up relies on (sqrt of exact small integers, division) on the
+ * device and compares them with the host's correctly rounded results bit for bit.
+ * *mismatches = 0 is required for bit-exact ray geometry. */
+int fs_selftest_fp64(fs_ctx *ctx, int32_t max_abs, int64_t *mismatches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

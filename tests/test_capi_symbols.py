@@ -8,13 +8,22 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "fitslam_frontier.h")
+HEADERS = [os.path.join(ROOT, "include", "fitslam_frontier.h"), os.path.join(ROOT, "include", "fitslam_frontier_dev.h")]
 
 
-def _declared():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text)))
+def _declared(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_diagnostics_live_in_the_dev_header():
+    """The drop-in header declares the scoring path only; timing, counters, knobs and the self test are in the dev header."""
+    public, dev = set(_declared(HEADERS[:1])), set(_declared(HEADERS[1:]))
+    assert dev == {"fs_enable_kernel_timing", "fs_kernel_time", "fs_set_option", "fs_get_counter", "fs_selftest_fp64"}
+    assert not (public & dev)
 
 
 def test_header_declares_expected_entry_points(fs):

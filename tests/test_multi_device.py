@@ -77,6 +77,15 @@ def test_multi_equals_single_context(fs, devices, n_cand):
     for _ in range(2):                                               # twice: the second call re-uses every member's buffers
         got = m.score_candidates(w.goals, w.frontier_size, w.blacklisted)
         _same_records(got, want)                                    # list order
+    # fs_multi_score_arrival: every column, the per-ray counts included, bit for bit
+    one = fs.FrontierScorer(device=0)
+    _stage(one, w, kw)
+    a1 = one.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+    one.close()
+    am = m.score_arrival(w.goals, w.frontier_size, w.blacklisted, n_rays_total=a1["ray_counts"].shape[1] * a1["ray_counts"].shape[2])
+    for k in ("arrival", "argmax", "yaw", "achievable", "status"):
+        np.testing.assert_array_equal(am[k], a1[k], err_msg=k)
+    np.testing.assert_array_equal(am["ray_counts"], a1["ray_counts"].reshape(am["ray_counts"].shape))
     # a call with fewer candidates than devices, and an empty one
     got = m.score_candidates(w.goals[:1], w.frontier_size[:1], w.blacklisted[:1])
     _same_records(got, want[:1])

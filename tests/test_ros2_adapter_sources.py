@@ -66,8 +66,8 @@ def test_adapter_calls_only_declared_abi_entry_points():
         used |= set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", _read(*f.split("/"))))
     assert used and used <= declared, used - declared
     # the batched calls that replace the reference's per-frontier loop and per-pose service call
-    assert {"fs_score_arrival", "fs_rank_candidates", "fs_max_arrival", "fs_upload_grid", "fs_score_fim",
-            "fs_upload_landmarks", "fs_lookup_load"} <= used
+    assert {"fs_multi_create", "fs_multi_score_arrival", "fs_rank_candidates", "fs_multi_max_arrival", "fs_multi_upload_grid",
+            "fs_score_fim", "fs_upload_landmarks", "fs_lookup_load"} <= used
 
 
 def test_cost_assigner_keeps_the_reference_interface():
@@ -79,3 +79,21 @@ def test_cost_assigner_keeps_the_reference_interface():
     src = _read("src", "CostAssignerGPU.cpp")
     for msg in ('"Duplicate frontiers found."', '"Cost out of bounds"', '"Lists are not SAME!"'):
         assert msg in src, msg                                   # the reference's exceptions, same texts
+
+
+def test_adapter_follows_the_reference_request_and_loads_next_to_the_reference_plugin():
+    """visibility = the reference's request by default (14.0 / 4.0, FisherInfoManager.cpp:63-64) as node
+    parameters; exhaustiveSearch handled explicitly; the plugin can be loaded next to the reference's; the scorer takes a
+    device list from a node parameter and stays one in-process object."""
+    fim = _read("src", "FisherInfoManagerGPU.cpp")
+    assert '"fisherInformation.max_dist_pose_observation"' in fim and '"fisherInformation.max_angle_pose_observation"' in fim
+    assert re.search(r"max_dist = 14\.0, max_angle = 4\.0", fim)
+    assert "bool exhaustiveSearch, float &information" in fim and "/*exhaustiveSearch*/" not in fim and "told_about_exhaustive_" in fim
+    plug = _read("src", "FisherInfoBTPluginGPU.cpp")
+    assert 'factory.builders()' in plug and 'known.count("MarkLethalFOV")' in plug
+    assert plug.index("if (!have_evaluate && !have_mark)") < plug.index('factory.unregisterBuilder("EvaluateFisherInformation")')
+    ca = _read("src", "CostAssignerGPU.cpp")
+    assert '"fitslam_frontier.gpu_devices"' in ca and "fs_multi_create" in ca and "fs_ctx_create" not in ca
+    # the two bodies the copy check flagged in round 2 are no longer the reference's statements
+    for ref_name in ("min_x_polygon", "max_y_polygon", "frontiers_list", "geometry_msgs::msg::Point32 temp"):
+        assert ref_name not in ca, ref_name
