@@ -64,7 +64,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time (three runs, median); 0 disables")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the measured configuration) | gloo (rehearsal of the N > 1 path on one GPU: ranks share the device, records are gathered through host memory)")
-    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="fs_set_option knobs, e.g. ray.layout=3")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="fs_set_option knobs, e.g. ray.layout=2")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: the ranks meet over gloo, all-gather a dummy record block and rank 0 prints a line marked dry_run (no value)")
     return ap.parse_args(argv)
 
@@ -292,10 +292,11 @@ def run_rank(args) -> int:
         c.set_ray_params(**arrival_kw)
         if bricks is not None:
             # configs[4]'s wire format: the non-unknown 8^3 bricks only; in HBM the grid is expanded to the dense image
-            # and its 8x8x2-brick copy (1 GiB + 1 GiB of 288 GB: no hash probe per cell on the ray walk).  Limit 2^31 cells.
+            # (1 GiB of 288 GB: no hash probe per cell on the ray walk; + 256 MiB of class image when long rays ask for it).
+            # Limit 2^31 cells.
             c.upload_grid_bricks(w.cells.shape, w.origin, w.resolution, bricks[0], bricks[1], default_value=255)
             grid_note = (f"sparse brick-list upload ({bricks[0].shape[0]} of {w.cells.size // 512} bricks), "
-                         "dense 1 GiB + bricked 1 GiB in HBM")
+                         "dense 1 GiB in HBM")
         else:
             c.upload_grid(w.cells, w.origin, w.resolution)
         c.upload_landmarks(w.landmarks)

@@ -89,10 +89,10 @@ struct fs_ctx {
 
     // grid
     bool have_grid = false;
-    DevBuf<uint8_t> d_cells, d_bricks, d_cells_t;   // dense row-major image, its 8x8x2-brick copy and its in-plane transpose (FsGridDev)
-    bool have_cells_t = false;                      // d_cells_t matches d_cells (built lazily: only "ray.layout" = 4 reads it)
-    DevBuf<uint8_t> d_cells_z;                      // [ny][nx][nz], the column image (built lazily: "ray.layout" = 5)
-    bool have_cells_z = false;
+    DevBuf<uint8_t> d_cells;                        // dense row-major image (FsGridDev)
+    DevBuf<uint32_t> d_cls;                         // 2-bit class image, cut lazily for cls_ranges (long rays only)
+    bool have_cls = false;
+    int32_t cls_ranges[4] = {0, 0, 0, 0};
     int32_t nx = 0, ny = 0, nz = 0;
     double origin[3] = {0, 0, 0};
     double res = 0.0;
@@ -169,7 +169,7 @@ struct fs_ctx {
     bool opt_costmap = true;       // the spatial sort puts the blocks that were expensive in the previous call first ("sort.costmap")
     const uint32_t *sort_keys = nullptr;   // this call's sort keys / the cost map inside sort_scratch (nullptr: list not sorted)
     uint32_t *sort_costmap = nullptr;
-    int opt_layout = 0;            // 0 auto, 1 row-major walk (a lane per ray), 2 bricked walk, 3 LDS-staged fan (planar fans; else auto), 4 span walk, 5 column walk
+    int opt_layout = 0;            // "ray.layout": 0 by ray length, 1 row-major byte walk, 2 class-image walk
 
     // timing
     bool timing = false;
@@ -394,29 +394,26 @@ void pose_to_rt(const double pose7[7], float Rt[12])
     Rt[9] = (float)pose7[0]; Rt[10] = (float)pose7[1]; Rt[11] = (float)pose7[2];
 }
 
-// Which copy of the grid a ray kernel walks: the bricked walk costs ~2x the integer work per step and touches 2-4x
-// fewer cache lines; measured on C3 it loses 12 % at L = 40 cells and wins 10 % at L = 160.  "ray.layout" forces one.
-int use_bricks(const fs_ctx *c, double max_length_cells)
+// Which image of the grid the arrival fan walks: the class walk costs ~1.5x the instructions per step and touches 4-8x fewer
+// cache lines; measured on C3 it loses 9 % at L = 40 cells and wins 29 % at L = 160.  "ray.layout" forces one.
+bool use_class_walk(const fs_ctx *c, double max_length_cells)
 {
-    if (c->opt_layout == 1) return 0;
-    if (c->opt_layout == 2) return 1;
-    return max_length_cells >= 96.0 ? 1 : 0;
+    if (c->opt_layout == 1) return false;
+    if (c->opt_layout == 2) return true;
+    return max_length_cells >= 96.0;
 }
 
 FsGridDev grid_dev(const fs_ctx *c)
 {
-    return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res,
-                     c->d_bricks.p, (c->nx + 7) >> 3, (c->ny + 7) >> 3, c->d_counters.p + 29, c->d_cells_t.p, c->d_cells_z.p};
+    return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res, c->d_counters.p + 29,
+                     c->have_cls ? c->d_cls.p : nullptr, 512u * (uint32_t)((c->nx + 15) >> 4) - 256u,
+                     512u * (uint32_t)((c->nx + 15) >> 4) * (uint32_t)((c->ny + 15) >> 4) - 512u};
 }
 
-// every upload path ends here: the ray kernels read the bricked copy
-int retile_grid(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz)
+// every upload path ends here: images derived from the grid are cut again on next use
+int retile_grid(fs_ctx *c, int32_t, int32_t, int32_t)
 {
-    const size_t bytes = (size_t)((nx + 7) >> 3) * (size_t)((ny + 7) >> 3) * (size_t)((nz + 1) >> 1) * FS_BRICK_BYTES;
-    FS_HIP(c, c->d_bricks.ensure(bytes));
-    FS_HIP(c, fs_launch_retile(c->d_cells.p, c->d_bricks.p, nx, ny, nz, c->stream));
-    c->have_cells_t = false;                         // the transposed image (span walk only) is rebuilt on demand
-    c->have_cells_z = false;
+    c->have_cls = false;
     return FS_OK;
 }
 
@@ -429,57 +426,28 @@ int check_scoring_state(fs_ctx *c, bool need_rays, bool need_fim)
     return FS_OK;
 }
 
-int fill_ray_args(fs_ctx *c, FsRayArgs &a)
+int fill_ray_args(fs_ctx *c, FsRayArgs &a, bool class_ok = true)
 {
     const fs_ray_params &p = c->rp;
     a.grid = grid_dev(c);
     a.dir = c->d_dir.p;
     a.n_yaw = c->n_yaw; a.n_elev = c->n_elev; a.window = c->window;
     a.max_length = (unsigned int)(p.max_camera_depth / c->res);             // CostCalculator.cpp:28
-    a.bricked = use_bricks(c, (double)a.max_length);
-    // Planar fans (one elevation ring at 0: the reference's own case) of up to 64 cells CAN walk an LDS copy of the
-    // start cell's neighbourhood (fs_raymarch.hip, WalkTile).  Measured on the reference defaults (REF2D: 512^2 map,
-    // 20 k fans of 63 rays, L = 40; profiles/r02/ref2d_ray_layouts.json): row-major 0.065 ms, bricked
-    // 0.084 ms, LDS-staged 0.081 ms — a 2-D map sits in L1/L2 and the kernel is bound by its per-fan set-up, so the
-    // automatic choice stays the row-major walk and the LDS walk is only taken on request ("ray.layout" = 3).
-    // Span walk (fs_raymarch.hip, span_fan): 16 lanes take 16 consecutive steps of ONE ray, read from the image whose rows
-    // run along the ray's major axis.  Needs the fan's descriptors in LDS (32 B per ray) and step counts that keep the
-    // division-free Bresenham positions exact.
-    // Measured on C3 (profiles/r02/c3_span_walk.json): 0.499 ms against 0.228 ms for the lane-per-ray walk — the lines per
-    // load do drop, but every lane now evaluates its cell from scratch (two multiply-highs and five multiplies per
-    // group of 16 steps, quarter-rate integer ops) where the lane-per-ray walk adds two offsets, so the kernel turns
-    // instruction-bound at twice the time.  Kept as a selectable layout ("ray.layout" = 4), never chosen automatically.
-    const bool span_ok = a.max_length >= 1 && a.max_length <= 1024 && (int64_t)c->n_yaw * c->n_elev <= 512;
-    if (span_ok && (c->opt_layout == 4 || c->opt_layout == 6)) {
-        if (!c->have_cells_t) {
-            const size_t total = (size_t)c->nx * (size_t)c->ny * (size_t)c->nz;
-            if (c->d_cells_t.ensure(total + 4) != hipSuccess || fs_launch_transpose(c->d_cells.p, c->d_cells_t.p, c->nx, c->ny, c->nz, c->stream) != hipSuccess)
-                return fail(c, FS_E_HIP, "could not stage the transposed grid image for the span walk");
-            c->have_cells_t = true;
-            a.grid = grid_dev(c);
+    // Long fans walk the class image, cut for exactly this visitor (the ray parameters' ranges; a launch with another visitor
+    // — fs_max_arrival — passes class_ok = false and walks the byte image).  It is cut on first use and again when the map or
+    // the ranges change: one streaming pass over the grid.
+    a.layout = 0;
+    if (class_ok && use_class_walk(c, (double)a.max_length)) {
+        const int32_t want[4] = {p.obst_min, p.obst_max, p.trace_min, p.trace_max};
+        if (!c->have_cls || std::memcmp(want, c->cls_ranges, sizeof want) != 0) {
+            if (c->d_cls.ensure(fs_class_image_words(c->nx, c->ny, c->nz)) != hipSuccess ||
+                fs_launch_classify(c->d_cells.p, c->d_cls.p, c->nx, c->ny, c->nz, want[0], want[1], want[2], want[3], c->stream) != hipSuccess)
+                return fail(c, FS_E_HIP, "could not stage the class image of the grid");
+            std::memcpy(c->cls_ranges, want, sizeof want);
+            c->have_cls = true;
         }
-        a.bricked = c->opt_layout == 6 ? 5 : 3;
-    }
-    // Column walk (fs_raymarch.hip, WalkColumn): the row-major walk on the z-fastest image with the elevation rings of a yaw
-    // in neighbouring lanes — 16 instead of ~38 lines per wave load.  Measured on C3 (profiles/r02/c3_column_walk.json):
-    // 0.286 against 0.226 ms: a column line is left after one step, the L1 misses more and the L2 -> L1 fill becomes the
-    // limit.  Selectable ("ray.layout" = 5), never chosen automatically.
-    if (c->opt_layout == 5 && c->nz > 1) {
-        if (!c->have_cells_z) {
-            const size_t total = (size_t)c->nx * (size_t)c->ny * (size_t)c->nz;
-            if (c->d_cells_z.ensure(total) != hipSuccess || fs_launch_columns(c->d_cells.p, c->d_cells_z.p, c->nx, c->ny, c->nz, c->stream) != hipSuccess)
-                return fail(c, FS_E_HIP, "could not stage the column image of the grid");
-            c->have_cells_z = true;
-            a.grid = grid_dev(c);
-        }
-        a.bricked = 4;
-    }
-    const bool planar = c->n_elev == 1 && p.elev[0] == 0.0;
-    if (planar && a.max_length >= 1 && a.max_length <= 64 && c->opt_layout == 3) {
-        a.bricked = 2;
-        a.tile_stride = (int32_t)((2 * a.max_length + 1 + 3 + 3) & ~3u);        // the row, + up to 3 cells of alignment slack, rounded up to 4
-        const uint32_t dw = (uint32_t)a.tile_stride / 4;
-        a.tile_magic = (uint32_t)((((uint64_t)1 << 32) + dw - 1) / dw);         // exact floor(i / dw) for i < 2^16 (i < 129 * 34)
+        a.grid = grid_dev(c);
+        a.layout = 1;
     }
     a.obst_min = p.obst_min; a.obst_max = p.obst_max; a.trace_min = p.trace_min; a.trace_max = p.trace_max;
     a.clamp = 1;
@@ -600,7 +568,7 @@ void fs_ctx_destroy(fs_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_bricks.release(); c->d_cells_t.release(); c->d_cells_z.release();
+    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_cls.release();
     c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
     c->d_kf_check.release(); c->d_kf_tri.release(); c->d_kf_off.release(); c->d_kf_flagged.release(); c->d_kf_cells.release();
@@ -743,7 +711,7 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
     if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
     if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
-    FS_HIP(c, c->d_cells.ensure((size_t)total + 4));       // (+4: the dword walk reads the aligned dword around the last cell)
+    FS_HIP(c, c->d_cells.ensure((size_t)total));
     FS_HIP(c, hipMemcpyAsync(c->d_cells.p, cells, (size_t)total, hipMemcpyHostToDevice, c->stream));
     {
         const int rc = retile_grid(c, nx, ny, nz);
@@ -767,7 +735,7 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
     if ((nx & 7) || (ny & 7) || (nz & 7)) return fail(c, FS_E_INVALID, "brick upload needs dimensions that are multiples of 8");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
     if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
-    FS_HIP(c, c->d_cells.ensure((size_t)total + 4));       // (+4: the dword walk reads the aligned dword around the last cell)
+    FS_HIP(c, c->d_cells.ensure((size_t)total));
     FS_HIP(c, hipMemsetAsync(c->d_cells.p, default_value, (size_t)total, c->stream));
     if (n_bricks > 0) {
         DevBuf<int32_t> &d_xyz = c->d_brick_xyz, &d_bad = c->d_bad;
@@ -889,7 +857,7 @@ int fs_max_arrival(fs_ctx *c, double *max_value, double *max_gt, double *min_gt)
     int rc = check_scoring_state(c, true, false);
     if (rc) return rc;
     FsRayArgs a{};
-    if (const int rc_args = fill_ray_args(c, a)) return rc_args;
+    if (const int rc_args = fill_ray_args(c, a, false)) return rc_args;     // (another visitor than the one a class image is cut for)
     // DEP/src/CostCalculator.cpp:140 visitor (260,260,0,255); :142-148 no clamping; start (0,0)
     a.obst_min = 260; a.obst_max = 260; a.trace_min = 0; a.trace_max = 255;
     a.clamp = 0;
@@ -1047,7 +1015,6 @@ int fs_trace_segments(fs_ctx *c, int32_t n, const double *start_xyz, const doubl
     FsSegArgs a{};
     a.grid = grid_dev(c);
     a.n = n; a.start = d_s.p; a.end = d_e.p; a.max_length = max_length_cells;
-    a.bricked = use_bricks(c, max_length_cells);
     a.obst_min = obst_min; a.obst_max = obst_max; a.trace_min = trace_min; a.trace_max = trace_max;
     a.ok = d_ok.p; a.hit = d_hit.p; a.traced = d_tr.p; a.unknown = d_un.p; a.all = d_all.p;
     FS_HIP(c, fs_launch_segments(a, c->stream));
@@ -1165,7 +1132,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 6) { c->opt_layout = (int)value; return FS_OK; }
+    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 2) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);

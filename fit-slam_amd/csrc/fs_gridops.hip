@@ -11,6 +11,8 @@
 //     The BFS clustering around it is graph traversal and stays on the host (out of scope).
 #include "fs_internal.h"
 
+#include <algorithm>
+
 namespace {
 
 __global__ void fs_brick_scatter_kernel(int64_t n_bricks, const int32_t *coords, const uint8_t *cells,
@@ -109,105 +111,46 @@ void fs_frontier_pair_kernel(int n, const float *lx, const float *ly, const floa
     if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// dense row-major grid -> 8 x 8 x 2 bricks (fs_internal.h): one thread moves the 8 cells of a brick row, which are
-// contiguous in both layouts
-__global__ void fs_retile_kernel(const uint8_t *__restrict__ cells, uint8_t *__restrict__ bricks, int nx, int ny, int nz)
+// dense row-major grid -> 2-bit class image in 16 x 16 x 2 tiles (fs_internal.h, FsGridDev::cls): one thread classifies the 16
+// cells of a tile row — contiguous in the row-major image — into one dword
+__global__ void fs_classify_kernel(const uint8_t *__restrict__ cells, uint32_t *__restrict__ cls, int nx, int ny, int nz,
+                                   int omin, int omax, int tmin, int tmax)
 {
-    const uint32_t nx8 = (uint32_t)(nx + 7) >> 3, bx = nx8, by = (uint32_t)(ny + 7) >> 3;
-    const long long total = (long long)nx8 * ny * nz;
+    const uint32_t tx = (uint32_t)(nx + 15) >> 4, ty = (uint32_t)(ny + 15) >> 4, tz = (uint32_t)(nz + 1) >> 1;
+    const long long total = (long long)tx * ty * tz * 32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const uint32_t x8 = (uint32_t)(i % nx8);
-        const long long r = i / nx8;
-        const uint32_t y = (uint32_t)(r % ny), z = (uint32_t)(r / ny);
-        const uint8_t *src = cells + ((size_t)z * ny + y) * nx + (size_t)x8 * 8;
-        uint8_t *dst = bricks + fs_brick_offset(bx, by, x8 * 8, y, z);
-        if ((nx & 7) == 0) {
-            *reinterpret_cast<unsigned long long *>(dst) = *reinterpret_cast<const unsigned long long *>(src);
-        } else {
-            const int n = min(8, nx - (int)x8 * 8);
-            for (int k = 0; k < n; ++k) dst[k] = src[k];
+        const uint32_t row = (uint32_t)(i & 31);                  // (z & 1) * 16 + (y & 15)
+        const long long tile = i >> 5;
+        const uint32_t bx = (uint32_t)(tile % tx), by = (uint32_t)((tile / tx) % ty), bz = (uint32_t)(tile / ((long long)tx * ty));
+        const int x0 = (int)(bx << 4), y = (int)((by << 4) | (row & 15u)), z = (int)((bz << 1) | (row >> 4));
+        uint32_t word = 0u;
+        if (y < ny && z < nz) {
+            const uint8_t *src = cells + ((size_t)z * ny + y) * nx;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int x = x0 + k;
+                const int c = x < nx ? (int)src[x] : -1;
+                const uint32_t code = ((c >= tmin && c <= tmax) ? 1u : 0u) | ((c >= omin && c <= omax) ? 2u : 0u);
+                word |= code << (2 * k);
+            }
         }
-    }
-}
-
-// dense row-major grid [z][y][x] -> its in-plane transpose [z][x][y] (the image y-major rays of the span walk read):
-// 32 x 32 tiles through LDS so that both the reads and the writes are coalesced
-__global__ void fs_transpose_kernel(const uint8_t *__restrict__ cells, uint8_t *__restrict__ cells_t, int nx, int ny, int nz)
-{
-    __shared__ uint8_t tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
-    const int tiles_x = (nx + 31) >> 5, tiles_y = (ny + 31) >> 5;
-    const long long n_tiles = (long long)tiles_x * tiles_y * nz;
-    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int bx = (int)(t % tiles_x);
-        const long long r = t / tiles_x;
-        const int by = (int)(r % tiles_y), z = (int)(r / tiles_y);
-        const size_t slice = (size_t)z * (size_t)ny * (size_t)nx;
-        for (int j = ty; j < 32; j += 8) {
-            const int x = bx * 32 + tx, y = by * 32 + j;
-            tile[j][tx] = (x < nx && y < ny) ? cells[slice + (size_t)y * nx + x] : (uint8_t)255;
-        }
-        __syncthreads();
-        for (int j = ty; j < 32; j += 8) {
-            const int x = bx * 32 + j, y = by * 32 + tx;
-            if (x < nx && y < ny) cells_t[slice + (size_t)x * ny + y] = tile[tx][j];
-        }
-        __syncthreads();
-    }
-}
-
-// dense row-major grid [z][y][x] -> the column image [y][x][z] (z runs fastest: the cells a fan's elevation rings visit above
-// one another share a cache line): per y, the (z, x) plane is transposed in 32 x 32 tiles through LDS
-__global__ void fs_columns_kernel(const uint8_t *__restrict__ cells, uint8_t *__restrict__ cells_z, int nx, int ny, int nz)
-{
-    __shared__ uint8_t tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
-    const int tiles_x = (nx + 31) >> 5, tiles_z = (nz + 31) >> 5;
-    const long long n_tiles = (long long)tiles_x * tiles_z * ny;
-    for (long long t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int bx = (int)(t % tiles_x);
-        const long long r = t / tiles_x;
-        const int bz = (int)(r % tiles_z), y = (int)(r / tiles_z);
-        for (int j = ty; j < 32; j += 8) {
-            const int x = bx * 32 + tx, z = bz * 32 + j;
-            tile[j][tx] = (x < nx && z < nz) ? cells[((size_t)z * ny + y) * (size_t)nx + x] : (uint8_t)255;
-        }
-        __syncthreads();
-        for (int j = ty; j < 32; j += 8) {
-            const int x = bx * 32 + j, z = bz * 32 + tx;
-            if (x < nx && z < nz) cells_z[((size_t)y * nx + x) * (size_t)nz + z] = tile[tx][j];
-        }
-        __syncthreads();
+        cls[i] = word;
     }
 }
 
 }  // namespace
 
-hipError_t fs_launch_columns(const uint8_t *d_cells, uint8_t *d_cells_z, int nx, int ny, int nz, hipStream_t s)
+size_t fs_class_image_words(int nx, int ny, int nz)
 {
-    const long long n_tiles = (long long)((nx + 31) >> 5) * ((nz + 31) >> 5) * ny;
-    if (n_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fs_columns_kernel, dim3((unsigned)(n_tiles < 65536 * 8 ? n_tiles : 65536 * 8)), dim3(256), 0, s,
-                       d_cells, d_cells_z, nx, ny, nz);
-    return hipGetLastError();
+    return (size_t)((nx + 15) >> 4) * (size_t)((ny + 15) >> 4) * (size_t)((nz + 1) >> 1) * 32;
 }
 
-hipError_t fs_launch_transpose(const uint8_t *d_cells, uint8_t *d_cells_t, int nx, int ny, int nz, hipStream_t s)
+hipError_t fs_launch_classify(const uint8_t *d_cells, uint32_t *d_cls, int nx, int ny, int nz, int obst_min, int obst_max,
+                              int trace_min, int trace_max, hipStream_t s)
 {
-    const long long n_tiles = (long long)((nx + 31) >> 5) * ((ny + 31) >> 5) * nz;
-    if (n_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fs_transpose_kernel, dim3((unsigned)(n_tiles < 65536 * 8 ? n_tiles : 65536 * 8)), dim3(256), 0, s,
-                       d_cells, d_cells_t, nx, ny, nz);
-    return hipGetLastError();
-}
-
-hipError_t fs_launch_retile(const uint8_t *d_cells, uint8_t *d_bricks, int nx, int ny, int nz, hipStream_t s)
-{
-    const long long total = (long long)((nx + 7) >> 3) * ny * nz;
-    if (total <= 0) return hipSuccess;
-    const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(fs_retile_kernel, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0, s,
-                       d_cells, d_bricks, nx, ny, nz);
+    const size_t words = fs_class_image_words(nx, ny, nz);
+    const int blocks = (int)std::min<size_t>((words + 255) / 256, 65535u * 16u);
+    hipLaunchKernelGGL(fs_classify_kernel, dim3(blocks), dim3(256), 0, s, d_cells, d_cls, nx, ny, nz, obst_min, obst_max, trace_min, trace_max);
     return hipGetLastError();
 }
 

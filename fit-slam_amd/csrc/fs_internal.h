@@ -20,31 +20,27 @@
 #endif
 
 // ---- ray-march kernel arguments ---------------------------------------------------------------
-// The occupancy grid lives in HBM twice: `cells` is the dense row-major image [nz][ny][nx] the uploads write (and the
-// frontier-cell stencil streams); `bricks` is the same grid cut into 8 x 8 x 2 bricks of 128 B = one cache line each,
-// which is what every ray walk reads: a ray crosses a brick in ~8 steps whatever its heading, so the lines touched per
-// ray (and per 64-lane load instruction of a fan) drop by 2-4x against rows that only help x-major rays.
+// The occupancy grid lives in HBM as the dense row-major image [nz][ny][nx] the uploads write — what short rays, the
+// footprint disc, the segment tracer and the frontier-cell stencil read — and, for long rays, as the CLASS image: what the
+// arrival visitor needs of a cell is two bits — in the trace range? in the obstacle range? (Helpers.hpp:64-71) — so the grid is
+// classified once per (map, visitor ranges) and packed 16 cells to a dword in tiles of 16 x 16 x 2 cells = 128 B = one cache
+// line: cell (x, y, z) is 2-bit field A & 15 of dword A >> 4,
+//     A = x + (x >> 4) * 496 + y * 16 + (y >> 4) * cls_my + z * 256 + (z >> 1) * cls_mz
+// (tile-linear order [z >> 1][y >> 4][x >> 4], cell order [z & 1][y & 15][x & 15]; 512^3 -> 32 MiB).
 struct FsGridDev {
     const uint8_t *cells;      // [nz][ny][nx]
     int32_t nx, ny, nz;
     double ox, oy, oz;         // origin
     double res;
-    const uint8_t *bricks;     // [ceil(nz/2)][by][bx][2][8][8]
-    int32_t bx, by;            // bricks per row / per column: ceil(nx/8), ceil(ny/8)
     unsigned long long *dbg;   // range-checked builds (FS_BOUNDS=1): where a walk that left the grid is recorded
-    const uint8_t *cells_t;    // [nz][nx][ny]: the in-plane transpose, read by y-major rays of the span walk
-    const uint8_t *cells_z;    // [ny][nx][nz]: z runs fastest — one cache line holds 128 cells of a COLUMN, read by the column walk
+    const uint32_t *cls;       // class image, or nullptr while it has not been cut
+    uint32_t cls_my, cls_mz;   // 512 * tiles_x - 256, 512 * tiles_x * tiles_y - 512
 };
 
-#define FS_BRICK_BYTES 128
-__host__ __device__ inline size_t fs_brick_offset(uint32_t bx, uint32_t by, uint32_t x, uint32_t y, uint32_t z)
-{
-    const uint32_t b = ((z >> 1) * by + (y >> 3)) * bx + (x >> 3);
-    return ((size_t)b << 7) | ((z & 1u) << 6) | ((y & 7u) << 3) | (x & 7u);
-}
-hipError_t fs_launch_retile(const uint8_t *d_cells, uint8_t *d_bricks, int nx, int ny, int nz, hipStream_t s);
-hipError_t fs_launch_transpose(const uint8_t *d_cells, uint8_t *d_cells_t, int nx, int ny, int nz, hipStream_t s);
-hipError_t fs_launch_columns(const uint8_t *d_cells, uint8_t *d_cells_z, int nx, int ny, int nz, hipStream_t s);
+// dwords of the class image of an nx x ny x nz grid, and the kernel that fills it (bit 0: cost in [trace_min, trace_max], bit 1: in [obst_min, obst_max])
+size_t fs_class_image_words(int nx, int ny, int nz);
+hipError_t fs_launch_classify(const uint8_t *d_cells, uint32_t *d_cls, int nx, int ny, int nz, int obst_min, int obst_max,
+                              int trace_min, int trace_max, hipStream_t s);
 
 struct FsRayArgs {
     FsGridDev grid;
@@ -56,11 +52,7 @@ struct FsRayArgs {
     uint32_t max_length;       // (unsigned)(max_camera_depth / resolution), CostCalculator.cpp:28
     int32_t obst_min, obst_max, trace_min, trace_max;
     int32_t clamp;             // CostCalculator.cpp:47-48 (1) or setMaxArrivalInformation (0)
-    int32_t bricked;           // 0: row-major image, 1: the 8x8x2-brick copy (long rays), 2: the fan's neighbourhood staged in LDS (planar fans),
-                               // 3: span walk (16 lanes = 16 consecutive steps of one ray, row-major image or its transpose by major axis),
-                               // 4: column walk (z-fastest image, the elevation rings of one yaw in neighbouring lanes)
-    int32_t tile_stride;       // LDS tile of layout 2: (2 * max_length + 1) rows of tile_stride bytes (a multiple of 4)
-    uint32_t tile_magic;       // ceil(2^32 / (tile_stride / 4)): row of a staged dword without an integer division
+    int32_t layout;            // 0: row-major byte image (WalkLinear), 1: class image (WalkClass)
     double lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // folded clamp bounds: max(poly_min, origin), min(poly_max, origin + sizeInMeters)
     double footprint_radius;   // ceil(robot_radius / resolution)
     double delta_theta, half_fov;
@@ -87,7 +79,6 @@ struct FsSegArgs {
     int32_t n;
     const double *start, *end;      // [n][3]
     double max_length;              // cells (the reference passes it as double)
-    int32_t bricked;
     int32_t obst_min, obst_max, trace_min, trace_max;
     uint8_t *ok, *hit;
     int32_t *traced, *unknown, *all;

@@ -15,15 +15,12 @@
 // wave-shuffle reduction.  This is HBM/L2-bound byte gather: no MFMA.
 #include "fs_internal.h"
 
-#include <type_traits>
-
 #ifndef FS_RAY_WAVES
 #define FS_RAY_WAVES 4          // candidates per workgroup
 #endif
 #ifndef FS_RAY_UNROLL
 #define FS_RAY_UNROLL 4         // speculative cell loads in flight per lane
 #endif
-#define FS_TILE_BATCH 7         // dwords per lane in flight while a fan's neighbourhood is staged into LDS
 
 namespace {
 
@@ -61,11 +58,12 @@ __device__ __forceinline__ bool world_to_map(const FsGridDev &g, double wx, doub
 
 __device__ __forceinline__ int sign_ref(int x) { return x > 0 ? 1 : -1; }   // Helpers.hpp:113-116
 
-// Three interchangeable walks over the same cell sequence (selected per launch, FsRayArgs::bricked):
+// Two interchangeable walks over the same cell sequence (selected per launch, FsRayArgs::layout; DESIGN.md 4.1 holds the
+// measurements, including the five other formulations that were built, measured and removed):
 //
 // WalkLinear — the reference's own formulation on the dense row-major image: a linear offset, constant strides per
-// axis, bresenham2D's body (DEP/src/Helpers.cpp:21-27) with a second minor axis.  Cheapest in ALU; rows only give
-// x-major rays any cache-line reuse.
+// axis, bresenham2D's body (DEP/src/Helpers.cpp:21-27) with a second minor axis.  Cheapest in instructions; rows only give
+// x-major rays any cache-line reuse.  The winner for short rays (up to ~96 cells).
 struct WalkLinear {
     uint32_t offset;
     uint32_t abs_da, abs_db, abs_dc;
@@ -74,23 +72,14 @@ struct WalkLinear {
     uint32_t end;            // min(max_length_steps, abs_da): loop visits, one more after the loop
 };
 
-// WalkColumn — the same walk on the column image [y][x][z] (z runs fastest): one cache line holds 128 cells of a column,
-// so the elevation rings of one yaw — which stand above one another at every step — share a line when they sit in
-// neighbouring lanes (the kernel deals rays to lanes ring-fastest for this walk).
-struct WalkColumn : WalkLinear {};
-
-// WalkDword — the lane-per-ray walk with FEWER loads: a ray reads the aligned 4-byte word around its cell from the image
-// whose rows run along its major axis (row-major image for x-major rays, the in-plane transpose for y-major ones) and
-// serves the following steps from that register for as long as they stay inside the word — up to four cells per load
-// for rays close to a grid axis, one per load for diagonal ones.
-struct WalkDword : WalkLinear { const uint8_t *img; };
-
-// WalkBricked — on the 8 x 8 x 2-brick copy, which has no constant strides: the walk keeps the cell coordinates and
-// applies the same body to every axis alike: an axis steps when its error term, advanced by |d_axis|, reaches
-// |d_major|.  The minor axes follow the reference's `error_b` exactly; for the major axis the term is advanced by
-// |d_major| itself and fires on every step — the unconditional `offset += offset_a`.  ~2x the integer work per
-// step, 2-4x fewer cache lines per ray: pays for long rays (measured cross-over between L = 40 and L = 160).
-struct WalkBricked {
+// WalkClass — on the 2-bit class image (FsGridDev::cls: 16 x 16 x 2 cells per cache line), which has no constant strides:
+// the walk keeps the cell coordinates and applies the Bresenham body to every axis alike — an axis steps when its error
+// term, advanced by |d_axis|, reaches |d_major|; the minor axes follow the reference's `error_b` exactly, for the major axis
+// the term is advanced by |d_major| itself and fires on every step (the unconditional `offset += offset_a`).  The cell's
+// address is separable, A = fx(x) + fy(y) + fz(z) with two operations per axis, and a cell arrives as its class — bit 0:
+// in the trace range, bit 1: in the obstacle range — so the visitor is two bit tests.  ~1.5x the instructions per step of
+// WalkLinear, 4-8x fewer cache lines per ray: loses 9 % at 40 cells, wins 29 % at 160 (C3).
+struct WalkClass {
     int x, y, z;
     int sgx, sgy, sgz;       // sign(dx) etc. with sign(0) = -1 (Helpers.hpp:113-116)
     uint32_t adx, ady, adz;
@@ -98,29 +87,6 @@ struct WalkBricked {
     int ex, ey, ez;
     uint32_t end;
 };
-
-// WalkTile — for PLANAR fans (one elevation ring at 0: the reference's 2-D case, DEP/src/CostCalculator.cpp:36-58): a
-// walk of at most L = max_length steps never leaves the (2L+1) x (2L+1) cells around the start cell, so the wave stages
-// that neighbourhood in LDS once per candidate (81 x 84 B = 6.8 KB at the reference's 2 m / 0.05 m) with coalesced
-// dword loads and every ray of the fan walks the LDS copy with bresenham2D's own two-axis body: one ds_read_u8 per step
-// instead of a 64-lane byte gather that touches ~40 cache lines.
-struct WalkTile {
-    const uint8_t *tile;     // LDS
-    uint32_t offset;
-    uint32_t abs_da, abs_db;
-    int err_b;
-    int off_a, off_b;
-    uint32_t end;
-};
-
-__device__ __forceinline__ void walk_step(WalkTile &w)
-{
-    w.offset += (uint32_t)w.off_a;
-    w.err_b += (int)w.abs_db;
-    if ((uint32_t)w.err_b >= w.abs_da) { w.offset += (uint32_t)w.off_b; w.err_b -= (int)w.abs_da; }
-}
-
-__device__ __forceinline__ int walk_cell(const FsGridDev &, const WalkTile &w) { return (int)w.tile[w.offset]; }
 
 __device__ __forceinline__ void walk_step(WalkLinear &w)
 {
@@ -131,10 +97,7 @@ __device__ __forceinline__ void walk_step(WalkLinear &w)
     if ((uint32_t)w.err_c >= w.abs_da) { w.offset += (uint32_t)w.off_c; w.err_c -= (int)w.abs_da; }
 }
 
-__device__ __forceinline__ void walk_step(WalkColumn &w) { walk_step(static_cast<WalkLinear &>(w)); }
-__device__ __forceinline__ void walk_step(WalkDword &w) { walk_step(static_cast<WalkLinear &>(w)); }
-
-__device__ __forceinline__ void walk_step(WalkBricked &w)
+__device__ __forceinline__ void walk_step(WalkClass &w)
 {
     w.ex += (int)w.adx;
     if ((uint32_t)w.ex >= w.abs_da) { w.x += w.sgx; w.ex -= (int)w.abs_da; }
@@ -154,19 +117,16 @@ __device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkLinear &w
 #endif
     return (int)g.cells[w.offset];
 }
-__device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkColumn &w)
+// the class (0..3) of the cell under the walk
+__device__ __forceinline__ uint32_t walk_class(const FsGridDev &g, const WalkClass &w)
 {
 #ifdef FS_RAY_BOUNDS
-    if (w.offset >= (uint32_t)g.nx * (uint32_t)g.ny * (uint32_t)g.nz) { atomicMax(g.dbg, 4ull); return 256; }
+    if ((uint32_t)w.x >= (uint32_t)g.nx || (uint32_t)w.y >= (uint32_t)g.ny || (uint32_t)w.z >= (uint32_t)g.nz) { atomicMax(g.dbg, 6ull); return 0u; }
 #endif
-    return (int)g.cells_z[w.offset];
-}
-__device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkBricked &w)
-{
-#ifdef FS_RAY_BOUNDS
-    if ((uint32_t)w.x >= (uint32_t)g.nx || (uint32_t)w.y >= (uint32_t)g.ny || (uint32_t)w.z >= (uint32_t)g.nz) { atomicMax(g.dbg, 2ull); return 256; }
-#endif
-    return (int)g.bricks[fs_brick_offset((uint32_t)g.bx, (uint32_t)g.by, (uint32_t)w.x, (uint32_t)w.y, (uint32_t)w.z)];
+    const uint32_t x = (uint32_t)w.x, y = (uint32_t)w.y, z = (uint32_t)w.z;
+    const uint32_t A = (x + (x >> 4) * 496u) + ((y << 4) + (y >> 4) * g.cls_my) + ((z << 8) + (z >> 1) * g.cls_mz);
+    const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(g.cls) + ((A >> 2) & ~3u));
+    return (word >> ((A & 15u) << 1)) & 3u;
 }
 
 // getTracedCells from the two map cells on (Helpers.cpp:46-94): `(unsigned)(scale * abs_da)` visits with
@@ -217,50 +177,7 @@ __device__ __forceinline__ void walk_init(WalkLinear &w, const FsGridDev &g, uin
     w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
 }
 
-__device__ __forceinline__ void walk_init(WalkColumn &w, const FsGridDev &g, uint32_t x0, uint32_t y0, uint32_t z0,
-                                          uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
-{
-    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
-    const uint32_t nx = (uint32_t)g.nx, nz = (uint32_t)g.nz;
-    w.offset = (y0 * nx + x0) * nz + z0;
-    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
-    const int odx = sign_ref(dx) * (int)nz, ody = sign_ref(dy) * (int)(nx * nz), odz = sign_ref(dz);
-    if (adx >= ady && adx >= adz) {                      // the same axis order as walk_init(WalkLinear): only the strides differ
-        w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
-    } else if (ady >= adz) {
-        w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz;
-    } else {
-        w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody;
-    }
-    w.err_b = w.err_c = (int)(w.abs_da / 2);
-    w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
-}
-
-__device__ __forceinline__ void walk_init(WalkDword &w, const FsGridDev &g, uint32_t x0, uint32_t y0, uint32_t z0,
-                                          uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
-{
-    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
-    const uint32_t nx = (uint32_t)g.nx, ny = (uint32_t)g.ny;
-    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
-    const bool xmaj = adx >= ady && adx >= adz, ymaj = !xmaj && ady >= adz;       // the axis order of walk_init(WalkLinear)
-    // y-major rays read the image whose rows run along y: [z][x][y]
-    const bool tr = ymaj;
-    const int stx = tr ? (int)ny : 1, sty = tr ? 1 : (int)nx, stz = (int)(nx * ny);
-    w.img = tr ? g.cells_t : g.cells;
-    w.offset = z0 * (uint32_t)stz + y0 * (uint32_t)sty + x0 * (uint32_t)stx;
-    const int odx = sign_ref(dx) * stx, ody = sign_ref(dy) * sty, odz = sign_ref(dz) * stz;
-    if (xmaj) {
-        w.abs_da = adx; w.abs_db = ady; w.abs_dc = adz; w.off_a = odx; w.off_b = ody; w.off_c = odz;
-    } else if (ymaj) {
-        w.abs_da = ady; w.abs_db = adx; w.abs_dc = adz; w.off_a = ody; w.off_b = odx; w.off_c = odz;
-    } else {
-        w.abs_da = adz; w.abs_db = adx; w.abs_dc = ady; w.off_a = odz; w.off_b = odx; w.off_c = ody;
-    }
-    w.err_b = w.err_c = (int)(w.abs_da / 2);
-    w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
-}
-
-__device__ __forceinline__ void walk_init(WalkBricked &w, const FsGridDev &, uint32_t x0, uint32_t y0, uint32_t z0,
+__device__ __forceinline__ void walk_init(WalkClass &w, const FsGridDev &, uint32_t x0, uint32_t y0, uint32_t z0,
                                           uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
 {
     const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
@@ -272,103 +189,15 @@ __device__ __forceinline__ void walk_init(WalkBricked &w, const FsGridDev &, uin
     w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
 }
 
-struct TileGeom {
-    uint8_t *tile;           // this wave's LDS tile
-    int x0, y0;              // grid cell of tile byte 0 (x0 a multiple of 4, possibly negative)
-    int stride;
-};
-
-__device__ __forceinline__ void walk_init(WalkTile &w, const TileGeom &t, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, double max_length)
-{
-    const int dx = (int)(x1 - x0), dy = (int)(y1 - y0);
-    w.tile = t.tile;
-    w.offset = (uint32_t)(((int)y0 - t.y0) * t.stride + ((int)x0 - t.x0));
-    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy);
-    const int odx = sign_ref(dx), ody = sign_ref(dy) * t.stride;
-    if (adx >= ady) { w.abs_da = adx; w.abs_db = ady; w.off_a = odx; w.off_b = ody; }      // Helpers.cpp:56-75
-    else { w.abs_da = ady; w.abs_db = adx; w.off_a = ody; w.off_b = odx; }                 // Helpers.cpp:77-93
-    w.err_b = (int)(w.abs_da / 2);
-    w.end = walk_visits(dx, dy, 0, w.abs_da, max_length);
-}
-
-// Stage the neighbourhood of the start cell (slice z0) into the wave's tile.  Cells beyond the grid are filled with
-// 255; they are never visited (a walk stays inside the bounding box of its two on-map end cells).
-__device__ __forceinline__ void stage_tile(const FsRayArgs &a, const TileGeom &t, uint32_t z0, int lane)
-{
-    const int nx = a.grid.nx, ny = a.grid.ny;
-    const int rows = 2 * (int)a.max_length + 1;
-    const uint8_t *slice = a.grid.cells + (size_t)z0 * (size_t)ny * (size_t)nx;
-    const int dw_per_row = t.stride >> 2;
-    uint32_t *tile32 = reinterpret_cast<uint32_t *>(t.tile);
-    const bool aligned = (nx & 3) == 0 && ((((size_t)ny * (size_t)nx) & 3) == 0);
-    // batches of FS_TILE_BATCH dwords per lane: all loads of a batch are issued before the first LDS store, so their
-    // latencies overlap (one load per iteration ran at one L2 round trip per 256 B)
-    const int total = rows * dw_per_row;
-    for (int base = 0; base < total; base += 64 * FS_TILE_BATCH) {
-        uint32_t v[FS_TILE_BATCH];
-#pragma unroll
-        for (int u = 0; u < FS_TILE_BATCH; ++u) {
-            const int i = base + u * 64 + lane;
-            const int r = (int)__umulhi((uint32_t)i, a.tile_magic);      // i / dw_per_row (exact: i < 2^16, see the launcher)
-            const int d = i - r * dw_per_row;
-            const int y = t.y0 + r, x = t.x0 + 4 * d;
-            v[u] = 0xffffffffu;
-            if (i < total && y >= 0 && y < ny) {
-                const uint8_t *row = slice + (size_t)y * (size_t)nx;
-                if (aligned && x >= 0 && x + 3 < nx) {
-                    v[u] = *reinterpret_cast<const uint32_t *>(row + x);
-                } else {
-                    uint32_t q = 0u;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int xb = x + b;
-                        const uint32_t c = (xb >= 0 && xb < nx) ? (uint32_t)row[xb] : 255u;
-                        q |= c << (8 * b);
-                    }
-                    v[u] = q;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < FS_TILE_BATCH; ++u) {
-            const int i = base + u * 64 + lane;
-            if (i < total) tile32[i] = v[u];
-        }
-    }
-}
-
-// WalkSpan — a tag: the fan is walked by span_fan below, where SIXTEEN LANES TAKE SIXTEEN CONSECUTIVE STEPS OF ONE RAY
-// (four rays per wave instruction) instead of one lane walking one ray.  Why: with a lane per ray a 64-lane byte load
-// touches one cache line per live ray (~40 at L = 40) and the kernel runs at the L1's line rate;
-// sixteen consecutive cells of a ray lie in one or two lines when they are read from the image whose rows run along the
-// ray's major axis — the row-major image for x-major rays, its in-plane transpose (FsGridDev::cells_t) for y-major
-// ones.  The cell of step s needs no loop: bresenham2D's error term advances by |d_minor| per step and wraps at
-// |d_major| (Helpers.cpp:21-27), so after s steps a minor axis has moved floor((|d_major| / 2 + s |d_minor|) / |d_major|)
-// cells — evaluated with a multiply-high by a per-ray reciprocal that is exact for the step counts admitted here
-// (fs_capi.hip: max_length <= 1024).  First-obstacle semantics are a ballot: a cell counts if it is in the trace range
-// and no lower step of its ray hit the obstacle range.
-struct WalkSpan {};
-
-#define FS_SPAN_WORDS 8      // per-ray descriptor in LDS: base, off_a, off_b, off_c, |da| | |db| << 16, |dc| | end << 16, magic, flags
-
 // The start cell is the same for every ray of a fan: its worldToMap (three fp64 divisions) is done once per candidate;
 // a start point off the map fails every ray, like the reference's `||` of the two conversions (Helpers.cpp:40).
 template <typename Walk>
-__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, const TileGeom &, bool start_ok, uint32_t x0, uint32_t y0, uint32_t z0,
+__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, bool start_ok, uint32_t x0, uint32_t y0, uint32_t z0,
                                           double wx, double wy, double wz, Walk &w)
 {
     uint32_t x1, y1, z1;
     if (!world_to_map(a.grid, wx, wy, wz, x1, y1, z1) || !start_ok) return false;
     walk_init(w, a.grid, x0, y0, z0, x1, y1, z1, (double)a.max_length);
-    return true;
-}
-// planar fan: the end cell lies in the start cell's slice (direction z component 0, the clamp keeps the cell)
-__device__ __forceinline__ bool ray_setup(const FsRayArgs &a, const TileGeom &t, bool start_ok, uint32_t x0, uint32_t y0, uint32_t,
-                                          double wx, double wy, double wz, WalkTile &w)
-{
-    uint32_t x1, y1, z1;
-    if (!world_to_map(a.grid, wx, wy, wz, x1, y1, z1) || !start_ok) return false;
-    walk_init(w, t, x0, y0, x1, y1, (double)a.max_length);
     return true;
 }
 
@@ -438,53 +267,36 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
     return count;
 }
 
-// The same visitor over the dword walk: four steps are laid out first (offsets only), a 4-byte word is loaded for every
-// step that leaves the word of the step before it, and the cells are cut out of the words.
-__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkDword w)
+// The visitor over the class image (the classes were cut with this launch's ranges: fs_capi.hip keeps them in step): bit 0
+// counts while no earlier cell of the ray carried bit 1 (Helpers.hpp:64-71 — the traced test comes before hit_obstacle is set,
+// so a cell in both ranges still counts).
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkClass w)
 {
-    const int omin = a.obst_min > 0 ? a.obst_min : 0, omax = a.obst_max < 255 ? a.obst_max : 255;
-    const int tmin = a.trace_min > 0 ? a.trace_min : 0, tmax = a.trace_max < 255 ? a.trace_max : 255;
-    const bool o_any = omax >= omin, t_any = tmax >= tmin;
-    const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
     int count = 0;
     uint32_t visits = w.end + 1;
-    uint32_t held_idx = 0xffffffffu, held = 0u;            // the word of the last step of the previous group
+    uint32_t open = 1u;                              // 1 until the first obstacle
+    while (visits >= FS_RAY_UNROLL) {
+        uint32_t c[FS_RAY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            c[u] = walk_class(a.grid, w);
+            walk_step(w);
+        }
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
+            count += (int)(c[u] & open);
+            open &= ~(c[u] >> 1);
+        }
+        if (!open) return count;
+        visits -= FS_RAY_UNROLL;
+    }
     while (visits > 0) {
-        const uint32_t nb = visits < FS_RAY_UNROLL ? visits : FS_RAY_UNROLL;
-        uint32_t off[FS_RAY_UNROLL], word[FS_RAY_UNROLL];
-        bool need[FS_RAY_UNROLL];
-#pragma unroll
-        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
-            off[u] = w.offset;
-            const uint32_t before = u ? (off[u - 1] >> 2) : held_idx;
-            need[u] = (uint32_t)u < nb && (off[u] >> 2) != before;
-            if ((uint32_t)u < nb) walk_step(w);
-        }
-#pragma unroll
-        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
-            word[u] = 0u;
-            if (need[u]) {
-#ifdef FS_RAY_BOUNDS
-                if ((off[u] | 3u) >= (uint32_t)a.grid.nx * (uint32_t)a.grid.ny * (uint32_t)a.grid.nz + 4u) { atomicMax(a.grid.dbg, 5ull); }
-                else
-#endif
-                word[u] = *reinterpret_cast<const uint32_t *>(w.img + (off[u] & ~3u));
-            }
-        }
-        bool hit = false;
-        uint32_t cur = held;
-#pragma unroll
-        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
-            cur = need[u] ? word[u] : cur;
-            held_idx = (uint32_t)u < nb ? (off[u] >> 2) : held_idx;
-            const int c = (uint32_t)u < nb ? (int)((cur >> ((off[u] & 3u) << 3)) & 0xffu) : -1;
-            const bool traced = t_any && !hit && (uint32_t)(c - tmin) <= trange;
-            count += traced ? 1 : 0;
-            hit = hit || (o_any && (uint32_t)(c - omin) <= orange);
-        }
-        if (hit) break;
-        held = cur;
-        visits -= nb;
+        const uint32_t c = walk_class(a.grid, w);
+        walk_step(w);
+        count += (int)(c & open);
+        open &= ~(c >> 1);
+        if (!open) break;
+        --visits;
     }
     return count;
 }
@@ -529,125 +341,9 @@ void fs_raymarch_kernel(const FsRayArgs a)
     bool fail = false;
     uint32_t sxm = 0, sym = 0, szm = 0;
     const bool start_ok = active && world_to_map(a.grid, sx, sy, sz, sxm, sym, szm);
-    constexpr bool kTile = std::is_same<Walk, WalkTile>::value;
-    constexpr bool kSpan = std::is_same<Walk, WalkSpan>::value;
-    TileGeom tg{nullptr, 0, 0, 0};
-    if (kTile) {
-        const int L = (int)a.max_length;
-        tg.stride = a.tile_stride;
-        tg.tile = reinterpret_cast<uint8_t *>(fs_ray_lds + FS_RAY_WAVES * a.n_yaw) + (size_t)wave * (size_t)(2 * L + 1) * (size_t)a.tile_stride;
-        tg.x0 = ((int)sxm - L) & ~3;                        // floor to a multiple of 4 (also for negative values)
-        tg.y0 = (int)sym - L;
-        if (start_ok && !black) stage_tile(a, tg, szm, lane);
-        wave_lds_fence();                                    // the tile is written and read by the same wave
-    }
-    if constexpr (kSpan) {
-        // ---- phase 1: every lane prepares the descriptors of its rays (fp64 end points exactly as below)
-        uint32_t *desc = reinterpret_cast<uint32_t *>(fs_ray_lds + FS_RAY_WAVES * a.n_yaw) + (size_t)wave * (size_t)n_rays * FS_SPAN_WORDS;
-        if (active && !black) {
-            const uint32_t nx = (uint32_t)a.grid.nx, ny = (uint32_t)a.grid.ny;
-            for (int r = lane; r < n_rays; r += 64) {
-                double wx = sx + a.dir[3 * r];               // DEP/src/CostCalculator.cpp:42-43
-                double wy = sy + a.dir[3 * r + 1];
-                double wz = sz + a.dir[3 * r + 2];
-                if (a.clamp) {                                  // :47-48
-                    wx = std_max(a.lo_x, std_min(a.hi_x, wx));
-                    wy = std_max(a.lo_y, std_min(a.hi_y, wy));
-                    wz = std_max(a.lo_z, std_min(a.hi_z, wz));
-                }
-                uint32_t x1, y1, z1;
-                const bool ok = world_to_map(a.grid, wx, wy, wz, x1, y1, z1) && start_ok;
-                uint32_t d[FS_SPAN_WORDS] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-                if (ok) {
-                    const int dx = (int)(x1 - sxm), dy = (int)(y1 - sym), dz = (int)(z1 - szm);
-                    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
-                    const bool xmaj = adx >= ady && adx >= adz, ymaj = !xmaj && ady >= adz;      // Helpers.cpp:56,77 with a third axis
-                    const uint32_t transposed = ymaj ? 1u : 0u;        // y-major rays read the image whose rows run along y
-                    const int stx = transposed ? (int)ny : 1, sty = transposed ? 1 : (int)nx, stz = (int)(nx * ny);
-                    const int ox_ = sign_ref(dx) * stx, oy_ = sign_ref(dy) * sty, oz_ = sign_ref(dz) * stz;
-                    uint32_t da, db, dc; int oa, ob, oc;
-                    if (xmaj) { da = adx; db = ady; dc = adz; oa = ox_; ob = oy_; oc = oz_; }
-                    else if (ymaj) { da = ady; db = adx; dc = adz; oa = oy_; ob = ox_; oc = oz_; }
-                    else { da = adz; db = adx; dc = ady; oa = oz_; ob = ox_; oc = oy_; }
-                    const uint32_t end = walk_visits(dx, dy, dz, da, (double)a.max_length);
-                    // ceil(2^32 / da) (exact in fp64 for da <= 2^11); da == 1: 2^31 with the numerator doubled (flag bit 2)
-                    uint32_t magic = 0u, unit = 0u;
-                    if (da == 1u) { magic = 0x80000000u; unit = 1u; }
-                    else if (da > 1u) magic = (uint32_t)ceil(4294967296.0 / (double)da);
-                    d[0] = szm * (uint32_t)stz + sym * (uint32_t)sty + sxm * (uint32_t)stx;
-                    d[1] = (uint32_t)oa; d[2] = (uint32_t)ob; d[3] = (uint32_t)oc;
-                    d[4] = da | (db << 16); d[5] = dc | (end << 16);
-                    d[6] = magic; d[7] = 1u | (transposed << 1) | (unit << 2);
-                } else {
-                    fail = true;
-                }
-                uint4 *dst = reinterpret_cast<uint4 *>(desc + (size_t)r * FS_SPAN_WORDS);
-                dst[0] = make_uint4(d[0], d[1], d[2], d[3]);
-                dst[1] = make_uint4(d[4], d[5], d[6], d[7]);
-            }
-        }
-        wave_lds_fence();                                    // descriptors are written and read by the same wave
-        // ---- phase 2: four rays per wave instruction, sixteen consecutive steps each
-        if (active && !black) {
-            const int omin = a.obst_min > 0 ? a.obst_min : 0, omax = a.obst_max < 255 ? a.obst_max : 255;
-            const int tmin = a.trace_min > 0 ? a.trace_min : 0, tmax = a.trace_max < 255 ? a.trace_max : 255;
-            const bool o_any = omax >= omin, t_any = tmax >= tmin;
-            const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
-            const int row = lane >> 4, sl = lane & 15;
-            const uint32_t below = (1u << sl) - 1u;                       // lower steps of my ray within a group
-            for (int q = 0; q < n_rays; q += 4) {
-                const int r = q + row;
-                uint4 d0 = make_uint4(0u, 0u, 0u, 0u), d1 = make_uint4(0u, 0u, 0u, 0u);
-                if (r < n_rays) {
-                    const uint4 *src = reinterpret_cast<const uint4 *>(desc + (size_t)r * FS_SPAN_WORDS);
-                    d0 = src[0]; d1 = src[1];
-                }
-                const uint32_t da = d1.x & 0xffffu, db = d1.x >> 16, dc = d1.y & 0xffffu, end = d1.y >> 16;
-                const uint32_t sh = (d1.w >> 2) & 1u, e0 = da >> 1;
-                const uint8_t *img = (d1.w & 2u) ? a.grid.cells_t : a.grid.cells;
-                bool alive = (d1.w & 1u) != 0u;
-                int count = 0;
-                for (uint32_t g0 = 0; ; g0 += 16) {
-                    const uint32_t s = g0 + (uint32_t)sl;
-                    const bool in = alive && s <= end;
-                    if (!__any(in)) break;
-                    // cells moved along the two minor axes after s steps (see the comment at WalkSpan)
-                    const uint32_t nb = __umulhi((e0 + s * db) << sh, d1.z), nc = __umulhi((e0 + s * dc) << sh, d1.z);
-                    const uint32_t off = d0.x + s * d0.y + nb * d0.z + nc * d0.w;
-                    int c = -1;
-                    if (in) {
-#ifdef FS_RAY_BOUNDS
-                        if (off >= (uint32_t)a.grid.nx * (uint32_t)a.grid.ny * (uint32_t)a.grid.nz) { atomicMax(a.grid.dbg, 3ull); }
-                        else
-#endif
-                        c = (int)img[off];
-                    }
-                    const bool hit = o_any && (uint32_t)(c - omin) <= orange;
-                    const bool tr = t_any && (uint32_t)(c - tmin) <= trange;
-                    // my ray's 16 steps of this group within the wave-wide masks
-                    const unsigned long long hm = __ballot(hit);
-                    const uint32_t hseg = ((lane & 32) ? (uint32_t)(hm >> 32) : (uint32_t)hm) >> (lane & 16) & 0xffffu;
-                    // Helpers.hpp:64-71: the traced test comes before hit_obstacle is set, so the obstacle cell itself still counts
-                    const bool counted = tr && (hseg & below) == 0u;
-                    const unsigned long long cm = __ballot(counted);
-                    const uint32_t cseg = ((lane & 32) ? (uint32_t)(cm >> 32) : (uint32_t)cm) >> (lane & 16) & 0xffffu;
-                    count += __popc(cseg);
-                    alive = alive && hseg == 0u;                           // nothing is pushed after the first obstacle
-                }
-                if (sl == 0 && r < n_rays) {
-                    if (count) atomicAdd(&ysum[r % a.n_yaw], count);
-                    if (a.ray_counts) a.ray_counts[(size_t)c * n_rays + r] = count;
-                }
-            }
-        }
-    } else
     if (active && !black) {
-        constexpr bool kColumn = std::is_same<Walk, WalkColumn>::value;
-        for (int q = lane; q < n_rays; q += 64) {
-            // ray r = e * n_yaw + i.  The column walk deals the rays ring-fastest: lanes q, q + 1, .. hold the n_elev rings
-            // of one yaw, which visit cells of the same column at every step
-            const int r = kColumn ? (q % a.n_elev) * a.n_yaw + q / a.n_elev : q;
-            const int i = r % a.n_yaw;
+        for (int r = lane; r < n_rays; r += 64) {
+            const int i = r % a.n_yaw;                               // ray r = e * n_yaw + i
             // DEP/src/CostCalculator.cpp:42-43: wx = sx + (MAX_CAMERA_DEPTH * cos(theta))
             double wx = sx + a.dir[3 * r];
             double wy = sy + a.dir[3 * r + 1];
@@ -659,7 +355,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
             }
             Walk w;
             int count = 0;
-            if (ray_setup(a, tg, start_ok, sxm, sym, szm, wx, wy, wz, w)) count = ray_march(a, w);
+            if (ray_setup(a, start_ok, sxm, sym, szm, wx, wy, wz, w)) count = ray_march(a, w);
             else fail = true;
             if (count) atomicAdd(&ysum[i], count);
             if (a.ray_counts) a.ray_counts[(size_t)c * n_rays + r] = count;
@@ -696,10 +392,8 @@ void fs_raymarch_kernel(const FsRayArgs a)
             }
         }
     };
-    if (kTile && ri <= (int)a.max_length)        // the disc lies inside the staged square: read the LDS copy
-        scan_disc([&](uint32_t x, uint32_t y) -> int { return tg.tile[((int)y - tg.y0) * tg.stride + ((int)x - tg.x0)]; });
-    else
-        scan_disc([&](uint32_t x, uint32_t y) -> int { return a.grid.bricks[fs_brick_offset((uint32_t)a.grid.bx, (uint32_t)a.grid.by, x, y, szm)]; });
+    const uint8_t *slice = a.grid.cells + (size_t)szm * (size_t)a.grid.ny * (size_t)a.grid.nx;       // (needs the cost itself: 254)
+    scan_disc([&](uint32_t x, uint32_t y) -> int { return slice[(size_t)y * (size_t)a.grid.nx + x]; });
     lethal = __any(lethal);
     const int fsize = a.frontier_size ? a.frontier_size[c] : 0;
     if (lethal && (double)fsize < 10.0) ach = 0;           // CostCalculator.cpp:77-82
@@ -788,26 +482,7 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
     int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
     if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
-    if (a.bricked == 3) {
-        const size_t lds_s = lds + (size_t)FS_RAY_WAVES * (size_t)a.n_yaw * (size_t)a.n_elev * FS_SPAN_WORDS * sizeof(uint32_t);
-        auto kernel = fs_raymarch_kernel<WalkSpan>;
-        if (lds_s > 48 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds_s, s, a);
-    } else if (a.bricked == 2) {
-        const size_t tile = (size_t)(2 * a.max_length + 1) * (size_t)a.tile_stride;
-        const size_t lds_t = lds + FS_RAY_WAVES * tile;
-        auto kernel = fs_raymarch_kernel<WalkTile>;
-        if (lds_t > 48 * 1024) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds_t, s, a);
-    } else if (a.bricked == 5) hipLaunchKernelGGL(fs_raymarch_kernel<WalkDword>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
-    else if (a.bricked == 4) hipLaunchKernelGGL(fs_raymarch_kernel<WalkColumn>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
-    else if (a.bricked) hipLaunchKernelGGL(fs_raymarch_kernel<WalkBricked>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    if (a.layout == 1) hipLaunchKernelGGL(fs_raymarch_kernel<WalkClass>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else hipLaunchKernelGGL(fs_raymarch_kernel<WalkLinear>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();
 }
@@ -815,8 +490,8 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
 hipError_t fs_launch_segments(const FsSegArgs &a, hipStream_t s)
 {
     if (a.n <= 0) return hipSuccess;
-    if (a.bricked) hipLaunchKernelGGL(fs_segments_kernel<WalkBricked>, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(fs_segments_kernel<WalkLinear>, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+    // (the segment visitor reports unknown cells separately from its ranges: it needs the costs, hence the byte image)
+    hipLaunchKernelGGL(fs_segments_kernel<WalkLinear>, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -29,12 +29,9 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * "sort.costmap" (default 1): that sort puts the blocks of the map whose candidates were expensive in the previous call
  * first (the persistent FIM grid drains better; identical results); "sort.reverse" (default 0): reversed block order, a
  * knob for measuring how much the order matters.
- * "ray.layout" (default 0): which copy of the grid the ray walks read — 0 picks by ray length (row-major image below
- * 96 cells, 8x8x2-brick copy from there on: the measured winners), 1 / 2 force the row-major / bricked walk, 3 walks an
- * LDS copy of the start cell's neighbourhood where the fan is planar and at most 64 cells deep, 4 the span walk (sixteen
- * lanes take sixteen consecutive steps of one ray; row-major image or its transpose by major axis) for fans of at most
- * 512 rays and 1024 cells, else as 0; 5 the column walk on 3-D grids (z-fastest image, the elevation rings of a yaw in
- * neighbouring lanes) (identical results in every case; DESIGN.md 4.1 holds the measured table).
+ * "ray.layout" (default 0): which image of the grid the arrival fan walks — 0 picks by ray length (row-major byte image below
+ * 96 cells, the 2-bit class image in 16 x 16 x 2-cell tiles from there on: the measured winners), 1 / 2 force the byte / class
+ * walk (identical results in every case; DESIGN.md 4.1 holds the measured table).
  * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
  * landmarks scanned, in 32nds, that decides the number of scoring passes: DESIGN.md 4.2). */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);

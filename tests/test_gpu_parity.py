@@ -420,9 +420,9 @@ def test_information_for_pose_hbm_table_pass(fs, oracle, scorer):
 
 
 def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
-    """The row-major walk, the walk over the 8x8x2-brick copy, the LDS-staged fan and the span walk (16 lanes = 16 steps
-    of one ray, row-major image or its transpose) visit the same cells: bit-exact against the oracle and against each
-    other, for short and long rays, odd grid sizes (partial bricks) and arbitrary segments."""
+    """The row-major byte walk and the walk over the 2-bit class image (16 x 16 x 2-cell tiles) visit the same cells:
+    bit-exact against the oracle and against each other, for short and long rays, 2-D and 3-D grids; arbitrary segments on
+    odd grid sizes."""
     rng = np.random.default_rng(77)
     try:
         for name, depth_cells in (("C1_2D", 40), ("C1", 40), ("C2", 160)):
@@ -432,7 +432,7 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
             _setup_scorer(scorer, w)
             mx_o = oracle.max_arrival_information(G, P)
             want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], n_threads=8)
-            for layout in (1, 2, 3, 4, 5, 6, 0):                   # 3: LDS-staged fan where the fan is planar, else as 0; 4: span walk
+            for layout in (1, 2, 0):                               # 1 row-major byte image, 2 class image, 0 chosen by ray length
                 scorer.set_option("ray.layout", layout)
                 assert scorer.max_arrival() == mx_o
                 _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
@@ -444,7 +444,7 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
         lo = np.array(origin); hi = lo + np.array([43, 37, 5]) * 0.05
         a = rng.uniform(lo - 0.05, hi + 0.05, size=(500, 3)); b = rng.uniform(lo - 0.05, hi + 0.05, size=(500, 3))
         res = {}
-        for layout in (1, 2):
+        for layout in (1, 2):                                      # (segments always walk the byte image: the option must not matter)
             scorer.set_option("ray.layout", layout)
             res[layout] = scorer.trace_segments(a, b, 200, obst=(254, 254), trace=(0, 255))
         for k in ("ok", "traced", "hit", "unknown", "all"):
@@ -459,11 +459,11 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
         scorer.set_option("ray.layout", 0)
 
 
-def test_lds_staged_fan_walk_equals_the_other_walks(fs, oracle, scorer):
-    """Planar fans walk an LDS copy of the start cell's neighbourhood (WalkTile): per-ray counts, arrival, argmax, yaw,
-    achievability and status identical to the oracle and to the row-major walk — grids whose row length is not a
-    multiple of 4 (byte staging), goals at the map border (tile partly off the grid), goals off the map, depths 1..64,
-    a z slice of a 3-D grid, visitor ranges that overlap."""
+def test_class_image_walk_equals_the_row_major_walk(fs, oracle, scorer):
+    """The class-image walk (WalkClass): per-ray counts, arrival, argmax, yaw, achievability and status identical to the
+    oracle and to the row-major walk — grids whose sides are not multiples of the 16 x 16 x 2 tile, goals at the map border
+    and off the map, depths 1..64, a z slice of a 3-D grid, visitor ranges that overlap (a cell in both classes), and a change
+    of the ranges between calls (the image must be cut again)."""
     rng = np.random.default_rng(301)
     try:
         for nx, ny, nz, depth in ((101, 67, 1, 40), (96, 96, 1, 64), (50, 131, 1, 7), (64, 64, 3, 40), (33, 35, 1, 1)):
@@ -488,7 +488,7 @@ def test_lds_staged_fan_walk_equals_the_other_walks(fs, oracle, scorer):
                 mx_o = oracle.max_arrival_information(G, P)
                 want = oracle.arrival_information(G, P, goals, fsize, black, min_gt=mx_o["min_gt"], faithful=True)
                 res = {}
-                for layout in (3, 4, 1):
+                for layout in (2, 1):
                     scorer.set_option("ray.layout", layout)
                     assert scorer.max_arrival() == mx_o
                     res[layout] = scorer.score_arrival(goals, fsize, black, want_ray_counts=True)
