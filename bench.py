@@ -65,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the measured configuration) | gloo (rehearsal of the N > 1 path on one GPU: ranks share the device, records are gathered through host memory)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="fs_set_option knobs, e.g. ray.layout=2")
+    ap.add_argument("--latency", action="store_true", help="the drop-in operating point instead of the throughput line: p50 / p99 of ONE fs_score_candidates call (host buffers in, records out, synchronised) at 1 / 50 / 200 / 2000 frontiers on REF2D and C1, of fs_score_fim(n = 1) and of fs_frontier_clusters on a 512^2 costmap, each with the oracle's single-thread time beside it")
+    ap.add_argument("--latency-calls", type=int, default=300, help="calls per latency figure")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: the ranks meet over gloo, all-gather a dummy record block and rank 0 prints a line marked dry_run (no value)")
     return ap.parse_args(argv)
 
@@ -195,6 +197,92 @@ def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx):
 
 # ------------------------------------------------------------------ one rank
 
+# ------------------------------------------------------------------ latency at the reference's operating point
+
+def _percentiles(us):
+    a = np.sort(np.asarray(us))
+    return {"p50_us": float(a[len(a) // 2]), "p99_us": float(a[min(len(a) - 1, int(0.99 * len(a)))]), "min_us": float(a[0]), "calls": int(len(a))}
+
+
+def run_latency(args) -> int:
+    """The reference scores tens of frontiers per behaviour-tree tick (DEP/src/FrontierCostsManager.cpp:74-119) and ONE pose per
+    isPoseSafe (FIP/src/fisher_information/FisherInfoBTPlugin.cpp:24-57): what a drop-in user feels is the latency of one call."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    fs = importlib.import_module("fit-slam_amd")
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O   # CPU baseline beside every figure (never inside a timed GPU call)
+    O.build()
+    table = O.Table.generate()
+    out = {"metric": "latency of one scoring call at the reference's operating point (host buffers in, results out, synchronised)",
+           "unit": "us", "calls_per_figure": args.latency_calls, "workloads": {}}
+    for wl in ("REF2D", "C1"):
+        w = fs.synth.make_workload(wl, n_cand=2000)
+        kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+                  robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+        sc = fs.FrontierScorer(device=0)
+        sc.set_ray_params(**kw); sc.upload_grid(w.cells, w.origin, w.resolution); sc.upload_landmarks(w.landmarks)
+        sc.lookup_generate(); sc.set_fim_params(14.0, 1.0)
+        mx = sc.max_arrival()
+        G = O.Grid(w.cells, origin=w.origin, resolution=w.resolution)
+        P = O.RayParams(**kw)
+        res = {"grid": list(w.cells.shape), "landmarks": int(w.landmarks.shape[0]), "rays_per_candidate": sc.n_yaw * sc.n_elev, "score_candidates": {}}
+        rec_all = None
+        for n in (1, 50, 200, 2000):
+            g, f, b = w.goals[:n], w.frontier_size[:n], w.blacklisted[:n]
+            for _ in range(20):
+                rec = sc.score_candidates(g, f, b)
+            ts = []
+            for _ in range(args.latency_calls):
+                t0 = time.perf_counter()
+                rec = sc.score_candidates(g, f, b)
+                ts.append((time.perf_counter() - t0) * 1e6)
+            if n == 2000:
+                rec_all = rec
+            t0 = time.perf_counter()
+            arr = O.arrival_information(G, P, g, f, b, min_gt=mx["min_gt"], faithful=True, n_threads=1, want_ray_counts=False)
+            fim = O.pose_information(table, w.landmarks, O.poses_from_yaw(g, arr["yaw"]), 14.0, 1.0, n_threads=1, want_f64=True)
+            cpu_us = (time.perf_counter() - t0) * 1e6
+            ok = bool(np.array_equal(rec["arrival"], arr["arrival"]) and np.array_equal(rec["n_visible"][arr["status"] == 0], fim["n_visible"][arr["status"] == 0]))
+            res["score_candidates"][str(n)] = dict(_percentiles(ts), cpu_oracle_1thread_us=cpu_us, parity_integers=ok)
+        # isPoseSafe: ONE pose (the pose of candidate 0 at its best yaw)
+        pose = O.poses_from_yaw(w.goals[:1], np.array([float(rec_all["yaw"][0])]))
+        for _ in range(20):
+            sc.score_fim(pose, want_fim=False)
+        ts = []
+        for _ in range(args.latency_calls):
+            t0 = time.perf_counter()
+            r1 = sc.score_fim(pose, want_fim=False)
+            ts.append((time.perf_counter() - t0) * 1e6)
+        t0 = time.perf_counter()
+        f1 = O.pose_information(table, w.landmarks, pose, 14.0, 1.0, n_threads=1, want_f64=False)
+        res["score_fim_1_pose"] = dict(_percentiles(ts), cpu_oracle_1thread_us=(time.perf_counter() - t0) * 1e6,
+                                       parity_integers=bool(r1["n_visible"][0] == f1["n_visible"][0]))
+        if wl == "REF2D":
+            # frontier detection + clustering on the 512^2 costmap, robot on a free cell (fs_frontier_clusters), and the whole
+            # FrontierSearch::searchFrom of the oracle (the reference's two nested breadth-first searches) beside it
+            y, x = np.argwhere(w.cells[0] == 0)[1234]
+            pos = (w.origin[0] + (x + 0.5) * w.resolution, w.origin[1] + (y + 0.5) * w.resolution)
+            for _ in range(10):
+                sc.frontier_clusters(w.cells.shape[1:], pos)
+            for labels in (True, False):
+                ts = []
+                for _ in range(max(50, args.latency_calls // 3)):
+                    t0 = time.perf_counter()
+                    _, cl, n_cl, n_cells = sc.frontier_clusters(w.cells.shape[1:], pos, want_labels=labels)
+                    ts.append((time.perf_counter() - t0) * 1e6)
+                res["frontier_clusters_with_labels" if labels else "frontier_clusters_records_only"] = dict(_percentiles(ts), clusters=int(n_cl), cells=int(n_cells))
+            t0 = time.perf_counter()
+            fr = O.frontier_search(w.cells, w.origin, w.resolution, pos)
+            res["frontier_clusters_with_labels"]["cpu_oracle_searchFrom_us"] = (time.perf_counter() - t0) * 1e6
+            res["frontier_clusters_with_labels"]["frontier_records"] = int(len(fr["sizes"]))
+        sc.close()
+        out["workloads"][wl] = res
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def dry_run(args, rank, world) -> int:
     """Rendezvous + the one collective of the N > 1 path with dummy records on the CPU (gloo): what a box without
     GPUs can check of the launcher.  Scores nothing and reports no value."""
@@ -321,11 +409,11 @@ def run_rank(args) -> int:
         k = state["k"]
         state["k"] += 1
         c, b = k % n_pipe, k % n_buf
-        if pending[b] is not None:
-            pending[b].wait()                                        # the gather that last read this buffer is done
-            pending[b] = None
         d_rec = d_recs[b]
         with torch.cuda.stream(streams[c]):
+            if pending[b] is not None:
+                pending[b].wait()                                    # (on streams[c]: the scorer below overwrites the buffer that gather read)
+                pending[b] = None
             scs[c].score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_rec.data_ptr())
             if world > 1:
                 if args.backend == "nccl":
@@ -388,6 +476,45 @@ def run_rank(args) -> int:
     multipass, tier3 = sum(c.get_counter(4) for c in scs), sum(c.get_counter(5) for c in scs)
     for c in scs:
         c.enable_kernel_timing(False)
+
+    # Two more operating points of the same workload, outside the timed region (N = 1 only), for the record:
+    #  * host-buffer path: fs_score_candidates with the candidate columns in host memory and the records back in host memory —
+    #    what a caller without device-resident buffers gets; PCIe both ways and one synchronisation per call included.
+    #    This rate is never `value`.
+    #  * cold cost map: the spatial sort puts blocks of the map whose candidates were expensive in the PREVIOUS call first
+    #    (DESIGN.md 4.1); the timed loop scores one list over and over, so its map is perfectly trained.  A call whose
+    #    predecessor recorded nothing (option sort.costmap off for one call) sees the empty map of a first call on a new snapshot.
+    extra = {}
+    if world == 1 and not args.no_parity:
+        g_h, f_h, b_h = w.goals[lo:hi], w.frontier_size[lo:hi], w.blacklisted[lo:hi]
+        for _ in range(3):
+            sc.score_candidates(g_h, f_h, b_h)
+        t0 = time.perf_counter()
+        reps_h = max(5, args.steps)
+        for _ in range(reps_h):
+            sc.score_candidates(g_h, f_h, b_h)
+        dt_h = (time.perf_counter() - t0) / reps_h
+        extra["host_buffer_path"] = {"ms_per_call": dt_h * 1e3, "candidate_goals_per_s": n_local / dt_h,
+                                     "note": "fs_score_candidates: candidate columns from host memory, records to host memory, one synchronisation per call (PCIe-inclusive; never `value`)"}
+        cold = []
+        for _ in range(7):
+            sc.set_option("sort.costmap", 0)
+            sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_recs[0].data_ptr())
+            sc.set_option("sort.costmap", 1)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_recs[0].data_ptr())
+            torch.cuda.synchronize(dev)
+            cold.append((time.perf_counter() - t0) * 1e3)
+        warm = []
+        for _ in range(7):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_recs[0].data_ptr())
+            torch.cuda.synchronize(dev)
+            warm.append((time.perf_counter() - t0) * 1e3)
+        extra["cold_costmap_step"] = {"ms_cold_median": float(np.median(cold)), "ms_trained_median_same_method": float(np.median(warm)),
+                                      "note": "single synchronised calls (launch latency included, unlike the back-to-back timed blocks): first call on an empty cost map against a call on the trained one"}
 
     if world > 1:
         tmax = torch.tensor(block_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -458,6 +585,7 @@ def run_rank(args) -> int:
                                     "from": "the last timed block (the only one with per-kernel hipEvents); with --pipeline > 1 "
                                             "a kernel's duration includes the time it shares the chip with the other stream's kernels"},
             "cpu_baseline": cpu, "parity": parity,
+            "other_operating_points": extra or None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -471,6 +599,8 @@ def run_rank(args) -> int:
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
+    if args.latency:
+        return run_latency(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)
     return run_rank(args)

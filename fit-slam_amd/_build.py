@@ -8,6 +8,7 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -121,23 +122,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src_path), hdr_t):
             cmd = [cc, *HIPCC_FLAGS, "-c", src_path, "-o", obj]
             if verbose:
-                print(" ".join(cmd), flush=True)
+                print(" ".join(cmd), file=sys.stderr, flush=True)
             res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
             usage = _parse_resource_remarks(res.stderr)
             rest = "\n".join(l for l in res.stderr.splitlines() if "kernel-resource-usage" not in l and l.strip())
             if rest:
-                print(rest, flush=True)
+                print(rest, file=sys.stderr, flush=True)       # (never stdout: bench.py's one JSON line lives there)
             if res.returncode != 0:
                 raise subprocess.CalledProcessError(res.returncode, cmd)
             _record_resources(src, usage)
         objs.append(obj)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(cmd), file=sys.stderr, flush=True)
+    subprocess.check_call(cmd, stdout=sys.stderr)
     return LIB
 
 
 if __name__ == "__main__":
-    import sys
     print(build(force="--force" in sys.argv, verbose=True))

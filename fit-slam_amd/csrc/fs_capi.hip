@@ -784,6 +784,7 @@ int fs_frontier_cells(fs_ctx *c, int32_t lethal_threshold, uint8_t *mask, int64_
     if (mask) FS_HIP(c, hipMemcpyAsync(mask, d_mask.p, total, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
     *count = (int64_t)n;
+    if (d_mask.cap > ((size_t)64 << 20)) d_mask.release();       // a whole-map mask (128 MB at 512^3, 1 GiB at 1024^3) is not worth keeping between ticks
     return FS_OK;
 }
 
@@ -827,19 +828,31 @@ int fs_frontier_clusters(fs_ctx *c, const double robot_xy[2], int32_t lethal_thr
                                               c->d_fc_state.p, labels ? c->d_fc_labels.p : nullptr, max_clusters, c->d_fc_clusters.p,
                                               c->d_fc_sums.p, c->stream));
     }
-    int32_t state[8];
-    FS_HIP(c, hipMemcpyAsync(state, c->d_fc_state.p, sizeof state, hipMemcpyDeviceToHost, c->stream));
-    if (labels) FS_HIP(c, hipMemcpyAsync(labels, c->d_fc_labels.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, c->stream));
+    // results through the page-locked buffer: the counters, the first clusters (as many as a map of this size usually has) and
+    // the labels are requested together and waited for once; only a map with more clusters costs a second round trip
+    const size_t first = (size_t)std::min<int32_t>(max_clusters, 4096);
+    const size_t o_state = 0, o_cl = 64, o_labels = (o_cl + first * sizeof(fs_frontier_cluster) + 63) & ~(size_t)63;
+    FS_HIP(c, c->h_out.ensure(o_labels + (labels ? sizeof(int32_t) * cells : 0)));
+    FS_HIP(c, hipMemcpyAsync(c->h_out.p + o_state, c->d_fc_state.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (first) FS_HIP(c, hipMemcpyAsync(c->h_out.p + o_cl, c->d_fc_clusters.p, first * sizeof(fs_frontier_cluster), hipMemcpyDeviceToHost, c->stream));
+    if (labels) FS_HIP(c, hipMemcpyAsync(c->h_out.p + o_labels, c->d_fc_labels.p, sizeof(int32_t) * cells, hipMemcpyDeviceToHost, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
+    int32_t state[8];
+    std::memcpy(state, c->h_out.p + o_state, sizeof state);
+    if (labels) std::memcpy(labels, c->h_out.p + o_labels, sizeof(int32_t) * cells);
     const int32_t stored = std::min(state[5], max_clusters);
     if (stored > 0) {
-        FS_HIP(c, hipMemcpyAsync(clusters, c->d_fc_clusters.p, sizeof(fs_frontier_cluster) * (size_t)stored, hipMemcpyDeviceToHost, c->stream));
-        FS_HIP(c, hipStreamSynchronize(c->stream));
+        std::memcpy(clusters, c->h_out.p + o_cl, sizeof(fs_frontier_cluster) * std::min<size_t>((size_t)stored, first));
+        if ((size_t)stored > first) {
+            FS_HIP(c, hipMemcpyAsync(clusters + first, c->d_fc_clusters.p + first, sizeof(fs_frontier_cluster) * ((size_t)stored - first), hipMemcpyDeviceToHost, c->stream));
+            FS_HIP(c, hipStreamSynchronize(c->stream));
+        }
         // slots were handed out in arrival order: present the clusters by ascending label
         std::sort(clusters, clusters + stored, [](const fs_frontier_cluster &u, const fs_frontier_cluster &v) { return u.label < v.label; });
     }
     *n_clusters = state[5];
     if (n_cells) *n_cells = state[6];
+    if (c->d_fc_labels.cap * sizeof(int32_t) > ((size_t)64 << 20)) c->d_fc_labels.release();   // (same rule as the stencil mask and the brick list)
     return FS_OK;
 }
 
@@ -1282,32 +1295,49 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!pose7 || !info_ref))) return fail(c, FS_E_INVALID, "null pose or output pointer");
     if (n == 0) return FS_OK;
-    std::vector<float> Rt((size_t)n * 12);
-    for (int32_t i = 0; i < n; ++i) pose_to_rt(pose7 + 7 * (size_t)i, &Rt[12 * (size_t)i]);
-    FS_HIP(c, c->d_Rt.ensure(Rt.size()));
-    FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, Rt.data(), Rt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    // One pose per call is the reference's operating point (FisherInfoBTPlugin.cpp:24-57), so the call's fixed cost matters: the
+    // pose records go through the context's page-locked buffer (one true DMA instead of a staged pageable copy) and every
+    // requested output column comes back through the other one — asynchronous copies, ONE synchronisation.
+    const size_t nn = (size_t)n;
+    FS_HIP(c, c->h_in.ensure(nn * 12 * sizeof(float)));
+    float *Rt = reinterpret_cast<float *>(c->h_in.p);
+    for (int32_t i = 0; i < n; ++i) pose_to_rt(pose7 + 7 * (size_t)i, Rt + 12 * (size_t)i);
+    FS_HIP(c, c->d_Rt.ensure(nn * 12));
+    FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, Rt, nn * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     rc = ensure_candidate_scratch(c, n, fim21 != nullptr);
     if (rc) return rc;
     FsFimArgs a{};
-    fill_fim_args(c, a);
+    if (const int rc_args = fill_fim_args(c, a)) return rc_args;
     a.n = n; a.Rt = c->d_Rt.p;
     // chunk culling reasons in world space and needs R orthonormal: a non-unit quaternion (which the
     // reference would feed to Eigen unnormalised) switches this call to the brute-force scan
     for (int32_t i = 0; i < n && a.cull; ++i) {
         const double *q = pose7 + 7 * (size_t)i + 3;
-        const double nn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-        if (!(std::fabs(nn - 1.0) <= 1.0e-4)) a.cull = 0;
+        const double nq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+        if (!(std::fabs(nq - 1.0) <= 1.0e-4)) a.cull = 0;
     }
     a.fim21 = fim21 ? c->d_fim21.p : nullptr;
     rc = run_fim(c, a);
     if (rc) return rc;
-    FS_HIP(c, hipMemcpyAsync(info_ref, c->d_info.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (fim21) FS_HIP(c, hipMemcpyAsync(fim21, c->d_fim21.p, sizeof(float) * 21 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (trace) FS_HIP(c, hipMemcpyAsync(trace, c->d_trace.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (logdet) FS_HIP(c, hipMemcpyAsync(logdet, c->d_logdet.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (n_visible) FS_HIP(c, hipMemcpyAsync(n_visible, c->d_nvis.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (n_voxels) FS_HIP(c, hipMemcpyAsync(n_voxels, c->d_nvox.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    struct Col { void *host; const void *dev; size_t bytes; };
+    const Col cols[6] = {{info_ref, c->d_info.p, 4 * nn}, {fim21, c->d_fim21.p, 84 * nn}, {trace, c->d_trace.p, 4 * nn},
+                         {logdet, c->d_logdet.p, 4 * nn}, {n_visible, c->d_nvis.p, 4 * nn}, {n_voxels, c->d_nvox.p, 4 * nn}};
+    size_t total = 0;
+    for (const Col &col : cols) if (col.host) total += (col.bytes + 15) & ~(size_t)15;
+    FS_HIP(c, c->h_out.ensure(total));
+    size_t off = 0;
+    for (const Col &col : cols) {
+        if (!col.host) continue;
+        FS_HIP(c, hipMemcpyAsync(c->h_out.p + off, col.dev, col.bytes, hipMemcpyDeviceToHost, c->stream));
+        off += (col.bytes + 15) & ~(size_t)15;
+    }
     FS_HIP(c, hipStreamSynchronize(c->stream));
+    off = 0;
+    for (const Col &col : cols) {
+        if (!col.host) continue;
+        std::memcpy(col.host, c->h_out.p + off, col.bytes);
+        off += (col.bytes + 15) & ~(size_t)15;
+    }
     return FS_OK;
 }
 

@@ -437,7 +437,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
         // ---- size and clear the hash table.  Distinct voxels are at most ~0.5 of the landmarks scanned (measured
         // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
-        // candidates clear only a small table.  The running voxel count in the main loop is the exact safety net.
+        // candidates clear only a small table.  The probe limit (FS_MAX_PROBE bucket visits) is the overflow detector.
         //
         // A candidate predicted to overfill the table is scored in n_parts PASSES over its accepted chunks: every pass
         // re-tests the landmarks but only queues those whose voxel belongs to the pass (voxel_part), so each landmark is
@@ -500,7 +500,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
         for (int part = 0; part < n_parts && !skip_tier; ++part) {
         if (part > 0) {
-            // next pass: everybody is done with the table -> clear it, restart the running voxel count
+            // next pass: everybody is done with the table -> clear it
             __syncthreads();
             const bool stop = __builtin_amdgcn_readfirstlane(overflow_flag()) != 0;   // uniform: nobody writes the flag between these barriers
             uint4 *t4 = reinterpret_cast<uint4 *>(table);

@@ -53,19 +53,27 @@ struct FcArgs {
     int32_t pos;                // the robot's cell
 };
 
-// per cell: is it expandable (T) / a frontier cell (F)?  parent arrays start as singletons (or -1 outside the set)
+// per cell: is it expandable (T) / a frontier cell (F)?  One wave takes 64 consecutive cells of a row (grid: ny rows x
+// ceil(nx / 64) segments).  F starts as singletons.  T starts linked by RUNS: the ballot of the T flags gives every lane the
+// start of its horizontal run inside the segment (the nearest non-T lane below it) — a smaller index of its own component,
+// written as its parent with a plain store before any union runs.
 __global__ void fs_fc_classify_kernel(const FcArgs a)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.nx * a.ny) return;
-    const int y = i / a.nx, x = i - y * a.nx;
-    const int c = a.map[i];
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int segs = (a.nx + 63) >> 6;
+    const int y = wave / segs, seg = wave - y * segs;
+    if (y >= a.ny) return;
+    const int x = seg * 64 + lane;
+    const bool inside = x < a.nx;
+    const int i = y * a.nx + x;
+    const int c = inside ? (int)a.map[i] : 254;
     // :62-68 — cost below LETHAL_OBSTACLE and inside the search radius (same fp64 expression: mapToWorld, pow(.,2), sqrt)
     const double wx = a.ox + (x + 0.5) * a.res, wy = a.oy + (y + 0.5) * a.res;
     const double dx = a.px - wx, dy = a.py - wy;
-    const bool t = c < 254 && sqrt(dx * dx + dy * dy) < a.reach;
+    const bool t = inside && c < 254 && sqrt(dx * dx + dy * dy) < a.reach;
     bool f = false;
-    if (c == 255) {                                                         // :221
+    if (inside && c == 255) {                                               // :221
         bool has_free = false, has_lethal = false;
         auto look = [&](int j) {
             const int v = a.map[j];
@@ -78,31 +86,54 @@ __global__ void fs_fc_classify_kernel(const FcArgs a)
         if (y < a.ny - 1) look(i + a.nx);
         f = !has_lethal && has_free;                                        // :241-246
     }
-    a.parent_t[i] = t ? i : -1;
-    a.parent_f[i] = f ? i : -1;
-    a.aux[i] = -1;
-    if (i == 0) a.state[7] = 0x7fffffff;                                    // (reduced by the next kernel)
+    const unsigned long long bt = __ballot(t);
+    if (inside) {
+        const unsigned long long gaps = ~bt & (lane ? (~0ull >> (64 - lane)) : 0ull);   // non-T lanes below mine
+        const int start = gaps ? 64 - __builtin_clzll(gaps) : 0;                       // first lane of my run in this segment
+        a.parent_t[i] = t ? i - (lane - start) : -1;
+        a.parent_f[i] = f ? i : -1;
+        a.aux[i] = -1;
+    }
+    if (wave == 0 && lane == 0) a.state[7] = 0x7fffffff;                    // (reduced by the next kernel)
 }
 
-// forward neighbours only (each pair once): right, down (4-connected T); + down-left, down-right (8-connected F)
+// Unions.  T (the expandable cells, 4-connected) is large — the whole mapped free space — and a union per cell pair made
+// this kernel 0.31 ms on a 512^2 costmap: every atomic of a big component ends at the same few roots.  T arrives linked by
+// horizontal runs (classify kernel); what is left for atomics is one union per segment boundary a run crosses and one per
+// STRETCH in which a run touches the row below (the first cell of every maximal stretch of vertically adjacent pairs) —
+// runs, not cells.  F (the frontier cells, 8-connected) is
+// a sparse set of thin curves: a union per forward neighbour (right, down, down-left, down-right), each pair once.
+// Grid: ny rows x ceil(nx / 64) segments, one wave each.
 __global__ void fs_fc_union_kernel(const FcArgs a)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.nx * a.ny) return;
-    const int y = i / a.nx, x = i - y * a.nx;
-    const bool right = x < a.nx - 1, down = y < a.ny - 1, left = x > 0;
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int segs = (a.nx + 63) >> 6;
+    const int y = wave / segs, seg = wave - y * segs;
+    if (y >= a.ny) return;
+    const int x = seg * 64 + lane;
+    const bool inside = x < a.nx;
+    const int i = y * a.nx + x;
+    const bool down = y < a.ny - 1;
     // how far nearestFreeCell will have to look: its search is an unobstructed 8-connected flood from the robot's cell, i.e. it
     // reaches cells in rings of growing Chebyshev distance and stops in the first ring that holds a cell below the threshold
-    if ((int)a.map[i] < (a.lethal_threshold & 0xff)) {
+    if (inside && (int)a.map[i] < (a.lethal_threshold & 0xff)) {
         const int py = a.pos / a.nx, px = a.pos - py * a.nx;
         const int d = max(abs(x - px), abs(y - py));
         if (d < a.state[7]) atomicMin(&a.state[7], d);
     }
-    if (a.parent_t[i] >= 0) {
-        if (right && a.parent_t[i + 1] >= 0) uf_union(a.parent_t, i, i + 1);
-        if (down && a.parent_t[i + a.nx] >= 0) uf_union(a.parent_t, i, i + a.nx);
+    const bool t0 = inside && a.parent_t[i] >= 0;
+    const bool t1 = t0 && down && a.parent_t[i + a.nx] >= 0;
+    const unsigned long long both = __ballot(t1);
+    if (t0) {
+        // a run that enters from the previous segment: one union at the boundary
+        if (lane == 0 && seg > 0 && a.parent_t[i - 1] >= 0) uf_union(a.parent_t, i, i - 1);
+        // first cell of a stretch of vertical pairs (the pair to my left is not one; across a segment boundary the stretch
+        // simply starts again: one union more, never one less)
+        if (t1 && (lane == 0 || !((both >> (lane - 1)) & 1ull))) uf_union(a.parent_t, i, i + a.nx);
     }
-    if (a.parent_f[i] >= 0) {
+    if (inside && a.parent_f[i] >= 0) {
+        const bool right = x < a.nx - 1, left = x > 0;
         if (right && a.parent_f[i + 1] >= 0) uf_union(a.parent_f, i, i + 1);
         if (down && a.parent_f[i + a.nx] >= 0) uf_union(a.parent_f, i, i + a.nx);
         if (down && left && a.parent_f[i + a.nx - 1] >= 0) uf_union(a.parent_f, i, i + a.nx - 1);
@@ -247,8 +278,10 @@ hipError_t fs_launch_frontier_clusters(const uint8_t *d_map, int nx, int ny, dou
     FcArgs a{d_map, nx, ny, ox, oy, res, px, py, reach, lethal_threshold, d_parent_t, d_parent_f, d_aux, d_state, start_pos};
     const int n = nx * ny;
     const dim3 grid((n + 255) / 256), block(256);
-    hipLaunchKernelGGL(fs_fc_classify_kernel, grid, block, 0, s, a);
-    hipLaunchKernelGGL(fs_fc_union_kernel, grid, block, 0, s, a);
+    const long long row_waves = (long long)ny * ((nx + 63) >> 6);               // one wave per 64 cells of a row
+    const dim3 row_grid((unsigned)((row_waves + 3) / 4));
+    hipLaunchKernelGGL(fs_fc_classify_kernel, row_grid, block, 0, s, a);
+    hipLaunchKernelGGL(fs_fc_union_kernel, row_grid, block, 0, s, a);
     hipLaunchKernelGGL(fs_fc_flatten_kernel, grid, block, 0, s, a);
     hipLaunchKernelGGL(fs_fc_start_kernel, dim3(1), dim3(256), 0, s, a, d_queue, d_visited);
     hipLaunchKernelGGL(fs_fc_seed_kernel, grid, block, 0, s, a);

@@ -383,9 +383,12 @@ void fs_raymarch_kernel(const FsRayArgs a)
     auto scan_disc = [&](auto cell_at) {
         const float inv_side = 1.0f / (float)side;
         for (int t = lane; t < side * side; t += 64) {
-            // t / side and t % side without the integer division: exact for t < 2^22 (side <= 2048; larger discs divide)
-            const int row = side <= 2048 ? (int)(((float)t + 0.5f) * inv_side) : t / side;
-            const int dx = row - ri, dy = (t - row * side) - ri;
+            // t / side and t % side without the integer division: the float quotient is within one of the true row for
+            // t < 2^22 (side <= 2048; larger discs divide), and one step on the remainder makes it exact
+            int row = side <= 2048 ? (int)(((float)t + 0.5f) * inv_side) : t / side;
+            int col = t - row * side;
+            if (col < 0) { --row; col += side; } else if (col >= side) { ++row; col -= side; }
+            const int dx = row - ri, dy = col - ri;
             if ((double)(dx * dx + dy * dy) <= a.footprint_radius * a.footprint_radius) {
                 const uint32_t x = sxm + (uint32_t)dx, y = sym + (uint32_t)dy;
                 if (x < (uint32_t)a.grid.nx && y < (uint32_t)a.grid.ny && cell_at(x, y) == 254) lethal = true;

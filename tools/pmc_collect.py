@@ -118,7 +118,7 @@ def averages(rows, last=6):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc_r02"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc_r03"))
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--depth-cells", type=int, default=0)
     ap.add_argument("--skip-calib", action="store_true")
@@ -129,7 +129,13 @@ def main():
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
     have = available_counters(out)
-    bench = ["python3", os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--cpu-seconds", "0", "--no-parity"]
+    # The profiled program is the interpreter itself, by its real path: rocprofv3's preloaded library initialises the GPU before
+    # the program starts, so a PATH shim or wrapper (pyenv ...) would be an exec hop behind an initialised GPU.  For the same
+    # reason bench.py must stay a single process here: --gpus N > 1 would make it a launcher that spawns ranks under the profiler.
+    bad = [a for i, a in enumerate(args.bench_arg) if a.startswith("--gpus") and (a not in ("--gpus", "--gpus=1") or (a == "--gpus" and args.bench_arg[i + 1:i + 2] != ["1"]))]
+    if bad:
+        raise SystemExit("pmc_collect.py profiles one process: --gpus other than 1 is refused (profile the rank program, not the launcher)")
+    bench = [os.path.realpath(sys.executable), os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--cpu-seconds", "0", "--no-parity"]
     if args.depth_cells:
         bench += ["--depth-cells", str(args.depth_cells)]
     bench += args.bench_arg
