@@ -394,20 +394,28 @@ void pose_to_rt(const double pose7[7], float Rt[12])
     Rt[9] = (float)pose7[0]; Rt[10] = (float)pose7[1]; Rt[11] = (float)pose7[2];
 }
 
-// Which image of the grid the arrival fan walks: the class walk costs ~1.5x the instructions per step and touches 4-8x fewer
-// cache lines; measured on C3 it loses 9 % at L = 40 cells and wins 29 % at L = 160.  "ray.layout" forces one.
+// Which image of the grid the arrival fan walks.  The class walk spends ~1.3x the instructions per step and touches 4-8x fewer
+// cache lines (L2 -> L1 fill 4.4 GB -> 0.5 GB per C3 launch).  Measured (profiles/r03/ray_class_walk.json): on 3-D grids it wins
+// at every ray length (C3: 0.210 against 0.229 ms at 40 cells, 0.66 against 1.12 ms at 160); on a 2-D costmap a short fan lives
+// in L1 either way and the byte walk's cheaper set-up wins (REF2D: 0.059 against 0.073 ms) until the rays get long.
+// "ray.layout" forces one.
+#ifndef FS_CLASS_WALK_FROM
+#define FS_CLASS_WALK_FROM 96.0
+#endif
 bool use_class_walk(const fs_ctx *c, double max_length_cells)
 {
-    if (c->opt_layout == 1) return false;
+    // (the walk forms brick addresses with 24-bit multiplies: the largest brick stride, 512 * bricks_x * bricks_y, must fit)
+    const uint64_t stride = 512ull * (uint64_t)((c->nx + 7) >> 3) * (uint64_t)((c->ny + 7) >> 3);
+    if (c->opt_layout == 1 || stride >= (1ull << 24)) return false;
     if (c->opt_layout == 2) return true;
-    return max_length_cells >= 96.0;
+    return c->nz > 1 || max_length_cells >= FS_CLASS_WALK_FROM;
 }
 
 FsGridDev grid_dev(const fs_ctx *c)
 {
+    const uint32_t bx = (uint32_t)(c->nx + 7) >> 3, by = (uint32_t)(c->ny + 7) >> 3, bz = (uint32_t)(c->nz + 7) >> 3;
     return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res, c->d_counters.p + 29,
-                     c->have_cls ? c->d_cls.p : nullptr, 512u * (uint32_t)((c->nx + 15) >> 4) - 256u,
-                     512u * (uint32_t)((c->nx + 15) >> 4) * (uint32_t)((c->ny + 15) >> 4) - 512u};
+                     c->have_cls ? c->d_cls.p : nullptr, {512u - 8u, 512u * bx - 64u, 512u * bx * by - 512u}, 512u * bx * by * bz};
 }
 
 // every upload path ends here: images derived from the grid are cut again on next use

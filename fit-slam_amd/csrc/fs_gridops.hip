@@ -111,25 +111,24 @@ void fs_frontier_pair_kernel(int n, const float *lx, const float *ly, const floa
     if (threadIdx.x == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// dense row-major grid -> 2-bit class image in 16 x 16 x 2 tiles (fs_internal.h, FsGridDev::cls): one thread classifies the 16
-// cells of a tile row — contiguous in the row-major image — into one dword
+// dense row-major grid -> 2-bit class image in 8 x 8 x 8 bricks (fs_internal.h, FsGridDev::cls): one thread classifies the 16
+// cells of one dword — two x-rows of a brick — from the row-major image
 __global__ void fs_classify_kernel(const uint8_t *__restrict__ cells, uint32_t *__restrict__ cls, int nx, int ny, int nz,
                                    int omin, int omax, int tmin, int tmax)
 {
-    const uint32_t tx = (uint32_t)(nx + 15) >> 4, ty = (uint32_t)(ny + 15) >> 4, tz = (uint32_t)(nz + 1) >> 1;
-    const long long total = (long long)tx * ty * tz * 32;
+    const uint32_t bx = (uint32_t)(nx + 7) >> 3, by = (uint32_t)(ny + 7) >> 3, bz = (uint32_t)(nz + 7) >> 3;
+    const long long total = (long long)bx * by * bz * 32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const uint32_t row = (uint32_t)(i & 31);                  // (z & 1) * 16 + (y & 15)
-        const long long tile = i >> 5;
-        const uint32_t bx = (uint32_t)(tile % tx), by = (uint32_t)((tile / tx) % ty), bz = (uint32_t)(tile / ((long long)tx * ty));
-        const int x0 = (int)(bx << 4), y = (int)((by << 4) | (row & 15u)), z = (int)((bz << 1) | (row >> 4));
+        const uint32_t d = (uint32_t)(i & 31);                    // dword of the brick: (z & 7) * 4 + (y & 7) / 2
+        const long long brick = i >> 5;
+        const uint32_t ix = (uint32_t)(brick % bx), iy = (uint32_t)((brick / bx) % by), iz = (uint32_t)(brick / ((long long)bx * by));
+        const int x0 = (int)(ix << 3), y0 = (int)((iy << 3) | ((d & 3u) << 1)), z = (int)((iz << 3) | (d >> 2));
         uint32_t word = 0u;
-        if (y < ny && z < nz) {
-            const uint8_t *src = cells + ((size_t)z * ny + y) * nx;
+        if (z < nz) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int x = x0 + k;
-                const int c = x < nx ? (int)src[x] : -1;
+                const int x = x0 + (k & 7), y = y0 + (k >> 3);
+                const int c = (x < nx && y < ny) ? (int)cells[((size_t)z * ny + y) * nx + x] : -1;
                 const uint32_t code = ((c >= tmin && c <= tmax) ? 1u : 0u) | ((c >= omin && c <= omax) ? 2u : 0u);
                 word |= code << (2 * k);
             }
@@ -142,7 +141,7 @@ __global__ void fs_classify_kernel(const uint8_t *__restrict__ cells, uint32_t *
 
 size_t fs_class_image_words(int nx, int ny, int nz)
 {
-    return (size_t)((nx + 15) >> 4) * (size_t)((ny + 15) >> 4) * (size_t)((nz + 1) >> 1) * 32;
+    return (size_t)((nx + 7) >> 3) * (size_t)((ny + 7) >> 3) * (size_t)((nz + 7) >> 3) * 32;
 }
 
 hipError_t fs_launch_classify(const uint8_t *d_cells, uint32_t *d_cls, int nx, int ny, int nz, int obst_min, int obst_max,

@@ -23,10 +23,10 @@
 // The occupancy grid lives in HBM as the dense row-major image [nz][ny][nx] the uploads write — what short rays, the
 // footprint disc, the segment tracer and the frontier-cell stencil read — and, for long rays, as the CLASS image: what the
 // arrival visitor needs of a cell is two bits — in the trace range? in the obstacle range? (Helpers.hpp:64-71) — so the grid is
-// classified once per (map, visitor ranges) and packed 16 cells to a dword in tiles of 16 x 16 x 2 cells = 128 B = one cache
+// classified once per (map, visitor ranges) and packed 16 cells to a dword in bricks of 8 x 8 x 8 cells = 128 B = one cache
 // line: cell (x, y, z) is 2-bit field A & 15 of dword A >> 4,
-//     A = x + (x >> 4) * 496 + y * 16 + (y >> 4) * cls_my + z * 256 + (z >> 1) * cls_mz
-// (tile-linear order [z >> 1][y >> 4][x >> 4], cell order [z & 1][y & 15][x & 15]; 512^3 -> 32 MiB).
+//     A = x + (x >> 3) * cls_m[0] + (y << 3) + (y >> 3) * cls_m[1] + (z << 6) + (z >> 3) * cls_m[2]
+// (brick-linear order [z >> 3][y >> 3][x >> 3], cell order [z & 7][y & 7][x & 7]; 512^3 -> 32 MiB).
 struct FsGridDev {
     const uint8_t *cells;      // [nz][ny][nx]
     int32_t nx, ny, nz;
@@ -34,7 +34,8 @@ struct FsGridDev {
     double res;
     unsigned long long *dbg;   // range-checked builds (FS_BOUNDS=1): where a walk that left the grid is recorded
     const uint32_t *cls;       // class image, or nullptr while it has not been cut
-    uint32_t cls_my, cls_mz;   // 512 * tiles_x - 256, 512 * tiles_x * tiles_y - 512
+    uint32_t cls_m[3];         // 512 - 8, 512 * bricks_x - 64, 512 * bricks_x * bricks_y - 512  (brick stride of the axis minus 8 << l)
+    uint32_t cls_cells;        // cells the image holds (padded to whole bricks)
 };
 
 // dwords of the class image of an nx x ny x nz grid, and the kernel that fills it (bit 0: cost in [trace_min, trace_max], bit 1: in [obst_min, obst_max])

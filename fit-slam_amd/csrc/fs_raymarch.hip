@@ -72,19 +72,21 @@ struct WalkLinear {
     uint32_t end;            // min(max_length_steps, abs_da): loop visits, one more after the loop
 };
 
-// WalkClass — on the 2-bit class image (FsGridDev::cls: 16 x 16 x 2 cells per cache line), which has no constant strides:
-// the walk keeps the cell coordinates and applies the Bresenham body to every axis alike — an axis steps when its error
-// term, advanced by |d_axis|, reaches |d_major|; the minor axes follow the reference's `error_b` exactly, for the major axis
-// the term is advanced by |d_major| itself and fires on every step (the unconditional `offset += offset_a`).  The cell's
-// address is separable, A = fx(x) + fy(y) + fz(z) with two operations per axis, and a cell arrives as its class — bit 0:
-// in the trace range, bit 1: in the obstacle range — so the visitor is two bit tests.  ~1.5x the instructions per step of
-// WalkLinear, 4-8x fewer cache lines per ray: loses 9 % at 40 cells, wins 29 % at 160 (C3).
+// WalkClass — on the 2-bit class image (FsGridDev::cls: bricks of 8 x 8 x 8 cells = one 128-B cache line), which has no
+// constant strides.  The walk keeps the cell coordinates IN THE RAY'S OWN AXIS ORDER (a = major, b, c = minors): the major
+// coordinate steps unconditionally (the reference's `offset += offset_a`), the minors on their error terms exactly as
+// bresenham2D's `error_b` (DEP/src/Helpers.cpp:21-27).  A cell's address is separable over the axes,
+//     A = sum over v in (a, b, c) of v * l_v + (v >> 3) * m_v,
+// with per-lane constants (l, m) that say which grid axis v is — a shift and two full-rate 24-bit multiply-adds per
+// axis — and a cell arrives as its class (bit 0: in the trace range, bit 1: in the obstacle range), so the visitor is two
+// bit tests.  More instructions per step than WalkLinear, 4-8x fewer cache lines per ray.
 struct WalkClass {
-    int x, y, z;
-    int sgx, sgy, sgz;       // sign(dx) etc. with sign(0) = -1 (Helpers.hpp:113-116)
-    uint32_t adx, ady, adz;
-    uint32_t abs_da;         // max of the three
-    int ex, ey, ez;
+    uint32_t a, b, c;        // cell coordinates along the major and the two minor axes
+    int sga, sgb, sgc;       // sign(d) with sign(0) = -1 (Helpers.hpp:113-116)
+    uint32_t abs_da, adb, adc;
+    int eb, ec;
+    uint32_t la, lb, lc;     // 1 / 8 / 64: the cell stride of the axis inside a brick (x / y / z)
+    uint32_t ma, mb, mc;     // FsGridDev::cls_m[axis]: brick stride of the axis minus (8 << l)
     uint32_t end;
 };
 
@@ -97,14 +99,27 @@ __device__ __forceinline__ void walk_step(WalkLinear &w)
     if ((uint32_t)w.err_c >= w.abs_da) { w.offset += (uint32_t)w.off_c; w.err_c -= (int)w.abs_da; }
 }
 
+// one minor axis of the class walk: e += |d_minor|; if (e >= |d_major|) { v += sign; e -= |d_major|; } in five instructions —
+// the subtraction's borrow IS the comparison (v_sub_co_u32), the smaller of e and e - |d_major| (unsigned wrap) is the new
+// error term.  (The compiler spends a sixth on a separate compare.)
+__device__ __forceinline__ void minor_step(uint32_t &v, int &e, uint32_t ad, uint32_t da, int sg)
+{
+    uint32_t t;
+    asm("v_add_u32 %[e], %[e], %[ad]\n\t"
+        "v_sub_co_u32 %[t], vcc, %[e], %[da]\n\t"
+        "v_min_u32 %[e], %[e], %[t]\n\t"
+        "v_cndmask_b32 %[t], %[sg], 0, vcc\n\t"
+        "v_add_u32 %[v], %[v], %[t]"
+        : [e] "+v"(e), [v] "+v"(v), [t] "=&v"(t)
+        : [ad] "v"(ad), [da] "v"(da), [sg] "v"(sg)
+        : "vcc");
+}
+
 __device__ __forceinline__ void walk_step(WalkClass &w)
 {
-    w.ex += (int)w.adx;
-    if ((uint32_t)w.ex >= w.abs_da) { w.x += w.sgx; w.ex -= (int)w.abs_da; }
-    w.ey += (int)w.ady;
-    if ((uint32_t)w.ey >= w.abs_da) { w.y += w.sgy; w.ey -= (int)w.abs_da; }
-    w.ez += (int)w.adz;
-    if ((uint32_t)w.ez >= w.abs_da) { w.z += w.sgz; w.ez -= (int)w.abs_da; }
+    w.a += (uint32_t)w.sga;
+    minor_step(w.b, w.eb, w.adb, w.abs_da, w.sgb);
+    minor_step(w.c, w.ec, w.adc, w.abs_da, w.sgc);
 }
 
 // The cell under the walk.  Both end points are on the map (worldToMap succeeded) and a Bresenham walk between two
@@ -120,13 +135,20 @@ __device__ __forceinline__ int walk_cell(const FsGridDev &g, const WalkLinear &w
 // the class (0..3) of the cell under the walk
 __device__ __forceinline__ uint32_t walk_class(const FsGridDev &g, const WalkClass &w)
 {
+    // (24-bit multiplies run at full rate, 32-bit ones at a quarter of it; brick indices and strides are far below 2^24 —
+    // fs_capi.hip only selects this walk where they are)
+    // one multiply-add chain: v * (1 << l) + (v >> 3) * m per axis
+    uint32_t A = (uint32_t)__umul24(w.c >> 3, w.mc);
+    A = (uint32_t)__umul24(w.c, w.lc) + A;
+    A = (uint32_t)__umul24(w.b >> 3, w.mb) + A;
+    A = (uint32_t)__umul24(w.b, w.lb) + A;
+    A = (uint32_t)__umul24(w.a >> 3, w.ma) + A;
+    A = (uint32_t)__umul24(w.a, w.la) + A;
 #ifdef FS_RAY_BOUNDS
-    if ((uint32_t)w.x >= (uint32_t)g.nx || (uint32_t)w.y >= (uint32_t)g.ny || (uint32_t)w.z >= (uint32_t)g.nz) { atomicMax(g.dbg, 6ull); return 0u; }
+    if (A >= g.cls_cells) { atomicMax(g.dbg, 6ull); return 0u; }
 #endif
-    const uint32_t x = (uint32_t)w.x, y = (uint32_t)w.y, z = (uint32_t)w.z;
-    const uint32_t A = (x + (x >> 4) * 496u) + ((y << 4) + (y >> 4) * g.cls_my) + ((z << 8) + (z >> 1) * g.cls_mz);
     const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(g.cls) + ((A >> 2) & ~3u));
-    return (word >> ((A & 15u) << 1)) & 3u;
+    return __builtin_amdgcn_ubfe(word, A << 1, 2u);            // v_bfe_u32 takes the offset modulo 32: field A & 15
 }
 
 // getTracedCells from the two map cells on (Helpers.cpp:46-94): `(unsigned)(scale * abs_da)` visits with
@@ -177,15 +199,24 @@ __device__ __forceinline__ void walk_init(WalkLinear &w, const FsGridDev &g, uin
     w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
 }
 
-__device__ __forceinline__ void walk_init(WalkClass &w, const FsGridDev &, uint32_t x0, uint32_t y0, uint32_t z0,
+__device__ __forceinline__ void walk_init(WalkClass &w, const FsGridDev &g, uint32_t x0, uint32_t y0, uint32_t z0,
                                           uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
 {
     const int dx = (int)(x1 - x0), dy = (int)(y1 - y0), dz = (int)(z1 - z0);
-    w.x = (int)x0; w.y = (int)y0; w.z = (int)z0;
-    w.adx = (uint32_t)abs(dx); w.ady = (uint32_t)abs(dy); w.adz = (uint32_t)abs(dz);
-    w.sgx = sign_ref(dx); w.sgy = sign_ref(dy); w.sgz = sign_ref(dz);
-    w.abs_da = w.adx >= w.ady ? (w.adx >= w.adz ? w.adx : w.adz) : (w.ady >= w.adz ? w.ady : w.adz);
-    w.ex = w.ey = w.ez = (int)(w.abs_da / 2);
+    const uint32_t adx = (uint32_t)abs(dx), ady = (uint32_t)abs(dy), adz = (uint32_t)abs(dz);
+    const int sx = sign_ref(dx), sy = sign_ref(dy), sz = sign_ref(dz);
+    // the axis order of walk_init(WalkLinear): the first largest extent is the major axis
+    if (adx >= ady && adx >= adz) {
+        w.a = x0; w.b = y0; w.c = z0; w.sga = sx; w.sgb = sy; w.sgc = sz; w.abs_da = adx; w.adb = ady; w.adc = adz;
+        w.la = 1; w.lb = 8; w.lc = 64; w.ma = g.cls_m[0]; w.mb = g.cls_m[1]; w.mc = g.cls_m[2];
+    } else if (ady >= adz) {
+        w.a = y0; w.b = x0; w.c = z0; w.sga = sy; w.sgb = sx; w.sgc = sz; w.abs_da = ady; w.adb = adx; w.adc = adz;
+        w.la = 8; w.lb = 1; w.lc = 64; w.ma = g.cls_m[1]; w.mb = g.cls_m[0]; w.mc = g.cls_m[2];
+    } else {
+        w.a = z0; w.b = x0; w.c = y0; w.sga = sz; w.sgb = sx; w.sgc = sy; w.abs_da = adz; w.adb = adx; w.adc = ady;
+        w.la = 64; w.lb = 1; w.lc = 8; w.ma = g.cls_m[2]; w.mb = g.cls_m[0]; w.mc = g.cls_m[1];
+    }
+    w.eb = w.ec = (int)(w.abs_da / 2);
     w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
 }
 
@@ -311,8 +342,13 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef FS_RAY_WAVES_PER_EU
+#define FS_RAY_OCCUPANCY __attribute__((amdgpu_waves_per_eu(FS_RAY_WAVES_PER_EU)))
+#else
+#define FS_RAY_OCCUPANCY
+#endif
 template <typename Walk>
-__global__ __launch_bounds__(FS_RAY_WAVES * 64)
+__global__ __launch_bounds__(FS_RAY_WAVES * 64) FS_RAY_OCCUPANCY
 void fs_raymarch_kernel(const FsRayArgs a)
 {
     extern __shared__ int fs_ray_lds[];          // [FS_RAY_WAVES][n_yaw] per-yaw sums over the elevation rings
@@ -343,7 +379,9 @@ void fs_raymarch_kernel(const FsRayArgs a)
     const bool start_ok = active && world_to_map(a.grid, sx, sy, sz, sxm, sym, szm);
     if (active && !black) {
         for (int r = lane; r < n_rays; r += 64) {
-            const int i = r % a.n_yaw;                               // ray r = e * n_yaw + i
+            // ray r = e * n_yaw + i: one elevation ring per wave instruction.  (Dealing the class walk's rays ring-fastest — a
+            // sector of 64 / n_elev yaws per instruction, whose rays tend to end at the same wall — measured +-1 %: r03.)
+            const int i = r % a.n_yaw;
             // DEP/src/CostCalculator.cpp:42-43: wx = sx + (MAX_CAMERA_DEPTH * cos(theta))
             double wx = sx + a.dir[3 * r];
             double wy = sy + a.dir[3 * r + 1];
