@@ -133,7 +133,7 @@ struct fs_ctx {
     // hash tables
     DevBuf<uint32_t> d_gtable;
     int ghash_bits = 0;
-    static constexpr int kPool = 256;     // tier 3: one 1024-thread workgroup per CU
+    static constexpr int kPool = 64;      // tier 3 (rare: no candidate of C3 or C5 reaches it): 64 x 1024 threads — an empty launch of 256 cost 7.5 us per call
 
     // per-candidate scratch
     DevBuf<double> d_goal, d_yaw, d_len, d_head, d_cost, d_au, d_du, d_sums;
