@@ -321,13 +321,23 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkClass w)
         if (!open) return count;
         visits -= FS_RAY_UNROLL;
     }
-    while (visits > 0) {
-        const uint32_t c = walk_class(a.grid, w);
-        walk_step(w);
-        count += (int)(c & open);
-        open &= ~(c >> 1);
-        if (!open) break;
-        --visits;
+    if (visits > 0) {
+        // the last, partial group as ONE batch of independent loads (a loop of single visits would expose a load latency
+        // per step); slots past the ray's end hold class 0, which neither counts nor stops
+        uint32_t c[FS_RAY_UNROLL - 1];
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL - 1; ++u) {
+            c[u] = 0u;
+            if ((uint32_t)u < visits) {
+                c[u] = walk_class(a.grid, w);
+                walk_step(w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FS_RAY_UNROLL - 1; ++u) {
+            count += (int)(c[u] & open);
+            open &= ~(c[u] >> 1);
+        }
     }
     return count;
 }
