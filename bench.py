@@ -515,6 +515,18 @@ def run_rank(args) -> int:
             warm.append((time.perf_counter() - t0) * 1e3)
         extra["cold_costmap_step"] = {"ms_cold_median": float(np.median(cold)), "ms_trained_median_same_method": float(np.median(warm)),
                                       "note": "single synchronised calls (launch latency included, unlike the back-to-back timed blocks): first call on an empty cost map against a call on the trained one"}
+        # the caller's last step of the same pass: fs_rank_candidates over the records of one step (host columns in,
+        # host columns out; path lengths as the reference's planner would supply them — here the straight-line distance)
+        recs_h = sc.score_candidates(g_h, f_h, b_h)
+        pl = np.hypot(g_h[:, 0] - w.robot_pose[0], g_h[:, 1] - w.robot_pose[1]).astype(np.float64) if hasattr(w, "robot_pose") else np.full(n_local, 5.0)
+        ph = np.zeros(n_local, dtype=np.float64)
+        for _ in range(2):
+            sc.rank_candidates(recs_h, pl, ph, b_h)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sc.rank_candidates(recs_h, pl, ph, b_h)
+        extra["rank_candidates_call"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3,
+                                         "note": "fs_rank_candidates over one step's records: utilities, weighted cost and order, host columns both ways"}
 
     if world > 1:
         tmax = torch.tensor(block_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")

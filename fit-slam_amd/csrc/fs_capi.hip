@@ -396,7 +396,7 @@ void pose_to_rt(const double pose7[7], float Rt[12])
 
 // Which image of the grid the arrival fan walks.  The class walk spends ~1.3x the instructions per step and touches 4-8x fewer
 // cache lines (L2 -> L1 fill 4.4 GB -> 0.5 GB per C3 launch).  Measured (profiles/r03/ray_class_walk.json): on 3-D grids it wins
-// at every ray length (C3: 0.210 against 0.229 ms at 40 cells, 0.66 against 1.12 ms at 160); on a 2-D costmap a short fan lives
+// at every ray length (C3: 0.202 against 0.229 ms at 40 cells, 0.66 against 1.12 ms at 160); on a 2-D costmap a short fan lives
 // in L1 either way and the byte walk's cheaper set-up wins (REF2D: 0.059 against 0.073 ms) until the rays get long.
 // "ray.layout" forces one.
 #ifndef FS_CLASS_WALK_FROM

@@ -41,12 +41,6 @@
 #define FS_STAMP(k) do { } while (0)
 #endif
 
-// development: timing-only ablations of the worker (results are WRONG; bench with --no-parity).  FS_FIM_ABLATE = 1: no
-// hash-table work in a score call (block sums only); 2: no score calls at all; 3: no landmark tests either (cull only).
-#ifndef FS_FIM_ABLATE
-#define FS_FIM_ABLATE 0
-#endif
-
 #ifndef FS_T1_THREADS
 #define FS_T1_THREADS 512
 #endif
@@ -136,9 +130,6 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
                                               bool active, float px, float py, float pz, Acc &acc, bool &overflow)
 {
     acc.nvis += active ? 1 : 0;
-#if FS_FIM_ABLATE >= 2
-    return false;
-#endif
     bool in_table;
     const uint32_t key = voxel_key(a, active, px, py, pz, in_table);
     // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
@@ -178,9 +169,6 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
     uint32_t rank = 0u;
     bool is_new = false;
     bool done = !valid;
-#if FS_FIM_ABLATE == 1
-    done = true; rank = 1u;
-#endif
     for (uint32_t probe = 0; probe < max_probe; ++probe) {
         if (probe != 0u) {
             if (__all(done)) break;                                       // second round trips are rare
@@ -522,9 +510,6 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 mask &= mask - 1ull;
                 return id;
             };
-#if FS_FIM_ABLATE >= 3
-            mask = 0ull;
-#endif
             // (the prefetch is issued unconditionally — past the end of the mask it re-reads chunk 0 and the values are never
             // used: no branch, no zeroing of three registers per iteration)
             auto fetch = [&](int c, float &x, float &y, float &z) {

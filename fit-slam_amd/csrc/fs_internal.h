@@ -8,7 +8,7 @@
 #include "../../include/fitslam_frontier.h"
 #include "../../include/fitslam_frontier_dev.h"
 
-// Instrumentation paths (cycle stamps, schedule recorder, range checks, ablations) exist in FS_DEV builds only — the
+// Instrumentation paths (cycle stamps, schedule recorder, range checks) exist in FS_DEV builds only — the
 // builds fit-slam_amd/_build.py makes under a library name of their own when one of its FS_* knobs is set.
 #ifndef FS_DEV
 #undef FS_FIM_STAMPS
@@ -16,7 +16,6 @@
 #undef FS_FIM_SCHEDULE
 #undef FS_FIM_BOUNDS
 #undef FS_RAY_BOUNDS
-#undef FS_RAY_ABLATE
 #endif
 
 // ---- ray-march kernel arguments ---------------------------------------------------------------

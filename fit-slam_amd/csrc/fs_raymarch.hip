@@ -245,9 +245,6 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
     const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
     int count = 0;
     uint32_t visits = w.end + 1;          // loop visits + the one after the loop (Helpers.cpp:29)
-#ifdef FS_RAY_ABLATE                      // development, timing only: the fan's set-up and epilogue without the walk
-    visits = visits > 1000000u ? 1u : 0u;
-#endif
     // full groups of FS_RAY_UNROLL visits first: every visit of the group exists, so the loads and steps need no per-step
     // bounds (one exec mask per group instead of one per step); the remainder (< FS_RAY_UNROLL visits) goes through the guarded
     // loop below.  Loads past an obstacle are speculative but always inside the start/end bounding box, hence in the grid.
