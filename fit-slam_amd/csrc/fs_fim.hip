@@ -8,12 +8,14 @@
 // into chunks of 64 consecutive landmarks, each with a bounding sphere.  Persistent workgroups (two per CU) pull
 // candidates from a device-side cursor over the processing order (fs_sort.hip); per candidate:
 //   1. cull   — chunk k belongs to wave (k mod waves); every lane tests one chunk sphere against the
-//               visibility volume (range sphere + cone, conservative) and the wave walks the ballot mask.  Only a few per cent of a 512^3
-//               map's cloud survives, so the per-landmark work drops by an order of magnitude while the
+//               visibility volume (range sphere + cone, conservative); the ballots are the wave's accepted
+//               chunks.  Only a few per cent of a 512^3 map's cloud survives, so the per-landmark work drops by an order of magnitude while the
 //               visible set stays exactly the brute-force one (the exact predicate is re-evaluated
 //               per landmark).
-//   2. test   — one wave per accepted chunk: coalesced 256-B loads, p = R^T (w - t) in fp32 with the
-//               specified fma order, range + cone predicate (multiplications and compares only).
+//   2. test   — the wave's ballot masks become a flat list of accepted chunk ids in one register (lane j = the j-th
+//               accepted chunk) that is walked with v_readlane; per chunk coalesced 256-B loads (the next chunk's in
+//               flight), p = R^T (w - t) in fp32 with the specified fma order, range + cone predicate as the sign
+//               of one v_min3_f32 of three exact differences.
 //   3. compact— visible lanes push p into the wave's LDS queue (ballot + mbcnt); whenever 64 are queued
 //               the whole wave runs the expensive part at full lane utilisation.
 //   4. score  — voxel lattice index (fp32 fast path, exact fp64 re-evaluation only next to a rounding
@@ -21,8 +23,9 @@
 //               value, and the reference's per-voxel pointCount bookkeeping (:296-304) as an LDS hash
 //               table keyed by the lattice index: the returning LDS atomic that bumps the voxel's
 //               count is the landmark's rank k in its voxel -> crowding factor exp(1 - k^0.8)
-//               (FisherInfoManager.hpp:102-106).  Same multiset of (info_v, k) terms as the reference's
-//               sequential loop.  Unit-weight 6x6 FIM via the block form [[P/n^2,-S/n^2],[S/n^2,P]].
+//               (FisherInfoManager.hpp:102-106), looked up by the next call so that no call waits for its own
+//               atomics.  Same multiset of (info_v, k) terms as the reference's sequential loop.
+//               Unit-weight 6x6 FIM via the block form [[P/n^2,-S/n^2],[S/n^2,P]].
 //   5. reduce — DPP row reductions, LDS across waves, fp64 per quantity; fs_fim_finish_kernel assembles F,
 //               trace and the log det (pivots of the square-root-free Cholesky factorisation).
 // Hash tables: 2^14 LDS slots per 512-thread workgroup (two workgroups per CU).  A candidate predicted to hold more
@@ -65,7 +68,18 @@ struct Acc {
     fs_f2 AB[6];
     fs_f2 s01; float s2;          // sum p / n^2
     int nvis, nvox;
+    // The last score call's (table value, count before my add) per lane, both possibly still in flight: the crowding factor is
+    // looked up and the product added by the NEXT call (or by resolve_pending at the end of the pass), so no call waits for
+    // its own returning add, factor read and table gather.  pend_old = 0xffffffff: nothing pending (factor index clamps to 0.0f).
+    uint32_t pend_old; float pend_info;
 };
+
+__device__ __forceinline__ void resolve_pending(Acc &acc, const float *lfac)
+{
+    const uint32_t rank = (acc.pend_old & FS_SLOT_CNT_MASK) + 1u;           // 0xffffffff -> 2048 -> the table's last entry: 0.0f
+    const float fac = lfac[rank < FS_FACTOR_N ? rank : FS_FACTOR_N - 1];
+    acc.info += fac > 0.0f ? acc.pend_info * fac : 0.0f;
+}
 
 // base[idx] with a 32-bit BYTE offset: lets the load use the scalar-base + 32-bit vector-offset addressing form instead
 // of building a 64-bit address per lane (every array indexed this way is far below 4 GiB)
@@ -120,39 +134,40 @@ __device__ __forceinline__ int voxel_part(const FsFimArgs &a, bool active, float
     return (jx + 4096) & (n_parts - 1);
 }
 
-// Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch).
-// Written as predicated straight-line code (selects, no per-lane branches): the scalar unit, not the vector ALU,
-// limited the branchy version.  TABLE_FULL (no NaN holes inside the table box: every generated table) removes the
-// only dependence of the hash update on the gathered table value, so that load is first waited for at the very end.
-// Returns true when this landmark opened a new voxel entry.
+// Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch): voxel key,
+// dense-table gather, the FIM block sums, and the voxel's hash bucket — the reference's pointCount bookkeeping (:296-304).
+// The table is organised in buckets of four slots read with ONE 16-byte LDS load: at the load factors used (< 0.5) a
+// bucket almost never fills up, so nearly every landmark resolves with one read plus one or two atomics.
+//
+// Written with the scalar unit in mind.  Boolean logic on per-lane conditions compiles to mask arithmetic (s_and / s_or /
+// s_andn2 on 64-bit lane masks), and a scalar instruction costs a wave 8 cycles alone and up to 16 with four waves per
+// SIMD (tools/valu_mix_calib.hip) — more than any vector instruction here.  So the first bucket visit is straight-line
+// code under ONE exec region (the lanes with a voxel), conditions implied by construction are not re-ANDed, the slot
+// search and the saturation are integer minima, and the general probe loop with its loop-carried lane masks is entered
+// only when a lane is left over.
+//
+// Nothing here waits for this call's own returning add, factor read or table gather: the pair (table value, count before my
+// add) is parked in `acc` and turned into info_v * exp(1 - k^0.8) by the NEXT call (resolve_pending) — for tables without
+// NaN holes (TABLE_FULL: every generated table) the gather is not waited for inside the call at all.
 template <bool TABLE_FULL>
-__device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
+__device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
                                               bool active, float px, float py, float pz, Acc &acc, bool &overflow)
 {
     acc.nvis += active ? 1 : 0;
     bool in_table;
     const uint32_t key = voxel_key(a, active, px, py, pz, in_table);
-    // dense-table value (key miss -> NaN -> skipped, :90-94); the gather's latency overlaps everything below
     const float info_t = FS_BOUND(key < (uint32_t)(a.tx * a.ty * a.tz), 1) ? ldg32(a.table, key) : 0.0f;
-
     bool valid = in_table;
     if (!TABLE_FULL) valid = valid && (info_t == info_t);
-    // ---- the voxel's hash bucket (the reference's pointCount bookkeeping, :296-304).  The table is organised in
-    // buckets of four slots read with ONE 16-byte LDS load: at the load factors used (< 0.5) a bucket almost never
-    // fills up, so nearly every landmark resolves with one read plus one atomic instead of walking a probe chain.
     const uint32_t tag = (key + 1u) << FS_SLOT_CNT_BITS;
     const uint32_t bmask = (1u << (bits - 2)) - 1u;
     uint32_t hb = hash_key(key, bits - 2);
     (void)FS_BOUND(hb <= bmask, 5);
-    hb &= bmask;      // whatever the hash returns, the bucket index stays inside the table ("the 06:07 abort")
-    // (read by every lane: a lane without a voxel reads the bucket of key 0 and ignores it — cheaper than masking the load)
+    hb &= bmask;      // whatever the hash returns, the bucket index stays inside the table
     uint4 bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
-
-    // ---- unit-weight FIM block sums, F(p) = [[P/n^2, -S/n^2],[S/n^2, P]]; P's diagonal as a
-    // sum of squares (1 - ux^2 = uy^2 + uz^2): no per-landmark cancellation.  The zero vector has no Jacobian.
+    resolve_pending(acc, lfac);                                       // the previous call's landmarks
     {
         const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
-        // (hardware reciprocal, 1 ulp: these sums only feed trace / log det / the 6x6, all held to 1e-4)
         const float q = (active && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f;
         const fs_f2 pxy = {px, py};
         const fs_f2 qxy = pxy * (fs_f2){q, q};
@@ -164,60 +179,89 @@ __device__ __forceinline__ bool score_visible(const FsFimArgs &a, uint32_t *tabl
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc.AB[i] = __builtin_elementwise_fma((fs_f2){v[i], v[i]}, one_q, acc.AB[i]);
         acc.s01 += qxy; acc.s2 += qz;
+        // (pins the sums HERE, in the shadow of the bucket read: left alone the compiler sinks them below the probe)
+        asm volatile("" : "+v"(acc.AB[0]), "+v"(acc.AB[1]), "+v"(acc.AB[2]), "+v"(acc.AB[3]), "+v"(acc.AB[4]), "+v"(acc.AB[5]), "+v"(acc.s01), "+v"(acc.s2));
     }
-
-    uint32_t rank = 0u;
-    bool is_new = false;
-    bool done = !valid;
-    for (uint32_t probe = 0; probe < max_probe; ++probe) {
-        if (probe != 0u) {
-            if (__all(done)) break;                                       // second round trips are rare
-            if (!done) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
-        }
+    // ---- first bucket visit, straight-line
+    uint32_t pend = 0xffffffffu;      // count before my add (rank - 1); ~0: no term (factor index clamps to an entry that is 0.0f)
+    uint32_t n_won = 0u;
+    uint32_t res = 0u;                // > FS_SLOT_CNT_MASK: this visit did not resolve the lane
+    if (valid) {
         const uint32_t w0 = bk.x, w1 = bk.y, w2 = bk.z, w3 = bk.w;
-        // a slot holds my voxel iff it agrees with the tag above the count bits, i.e. slot ^ tag is a bare count (an empty
-        // slot never does: tag >= 2^11); at most one slot can, so the smallest of the four differences is that count
-        const uint32_t x0 = w0 ^ tag, x1 = w1 ^ tag, x2 = w2 ^ tag, x3 = w3 ^ tag;
-        const uint32_t xm3 = x0 < x1 ? (x0 < x2 ? x0 : x2) : (x1 < x2 ? x1 : x2);                       // v_min3_u32
-        const uint32_t xmin = xm3 < x3 ? xm3 : x3;
-        const bool has_match = xmin <= FS_SLOT_CNT_MASK;
-        const uint32_t jm = x0 == xmin ? 0u : (x1 == xmin ? 1u : (x2 == xmin ? 2u : 3u));
+        // a slot holds my voxel iff slot ^ tag is a bare count (an empty slot never is: tag >= 2^11).  The slot's index rides in
+        // the two lowest bits of the difference — the match test looks at bits >= 11, saturation at bit 10, the exact count
+        // comes back from the add — so the smallest of the four is the match AND says where it sits: no compare / select chain.
+        const uint32_t y0 = (w0 ^ tag) & ~3u, y1 = ((w1 ^ tag) & ~3u) | 1u, y2 = ((w2 ^ tag) & ~3u) | 2u, y3 = ((w3 ^ tag) & ~3u) | 3u;
+        const uint32_t ym3 = y0 < y1 ? (y0 < y2 ? y0 : y2) : (y1 < y2 ? y1 : y2);                       // v_min3_u32
+        const uint32_t ymin = ym3 < y3 ? ym3 : y3;
+        const bool has_match = ymin <= FS_SLOT_CNT_MASK;
         // slots fill in order: the first empty one is the number of occupied ones
-        // (v_min_u32 by hand: the compiler turns min(w, 1) back into a compare / add-with-carry chain through VCC, whose
-        // write-then-read hazards it pads with s_nop)
         uint32_t u0, u1, u2, u3;
         asm("v_min_u32 %0, 1, %1" : "=v"(u0) : "v"(w0));
         asm("v_min_u32 %0, 1, %1" : "=v"(u1) : "v"(w1));
         asm("v_min_u32 %0, 1, %1" : "=v"(u2) : "v"(w2));
         asm("v_min_u32 %0, 1, %1" : "=v"(u3) : "v"(w3));
         const uint32_t used = (u0 + u1) + (u2 + u3);
-        const bool can_insert = !has_match && used < 4u;
-        uint32_t *slot = table + (hb << 2) + (has_match ? jm : (used < 4u ? used : 0u));
+        uint32_t *slot = table + (hb << 2) + (has_match ? (ymin & 3u) : used);
         uint32_t prev = 0xffffffffu;
-        if (!done && can_insert) prev = atomicCAS(slot, 0u, tag | 1u);    // 0: this lane created the entry
-        const bool won = !done && can_insert && prev == 0u;
+        if (!has_match && used < 4u) prev = atomicCAS(slot, 0u, tag | 1u);    // 0: this lane created the entry
+        // prev: 0 = created; another slot word (>= 2^11) = somebody was faster; ~0 = no CAS.  prev ^ tag is a bare count iff the
+        // faster one brought MY voxel ("late": add to it).  None of this needs the masks of the conditions above re-ANDed:
+        // ~0 is not 0, and ~0 ^ tag is no bare count (keys stop two short of 2^21).
         const uint32_t xprev = prev ^ tag;
-        const bool late = !done && can_insert && prev != 0u && xprev <= FS_SLOT_CNT_MASK;   // my voxel just arrived there
-        const bool do_add = !done && (has_match || late);
-        const uint32_t cnt = has_match ? xmin : xprev;                     // the entry's count before my add
-        const bool sat = do_add && cnt >= FS_SLOT_CNT_SAT;                 // factor is 0.0f out there anyway
-        uint32_t old = 0u;
-        if (do_add && !sat) old = atomicAdd(slot, 1u);
-        const uint32_t add_rank = sat ? FS_SLOT_CNT_SAT + 1u : (old & FS_SLOT_CNT_MASK) + 1u;
-        rank = won ? 1u : (do_add ? add_rank : rank);
-        is_new = is_new || won;
-        const bool full = !done && !has_match && used >= 4u;              // bucket holds four other voxels: next bucket
-        hb = full ? ((hb + 1u) & bmask) : hb;
-        done = done || won || do_add;                                     // a lost CAS against another voxel re-reads the bucket
+        const uint32_t cnt = ymin < xprev ? ymin : xprev;                 // the count my voxel showed, wherever I found it
+        // rank - 1 for lanes that do not add: created -> 0 (prev), saturated -> FS_SLOT_CNT_SAT (the factor is 0.0f from rank 337 on
+        // and the count field must not run over); the add's return value replaces it for the others
+        uint32_t pnd = cnt < prev ? cnt : prev;
+        pnd = pnd < FS_SLOT_CNT_SAT ? pnd : FS_SLOT_CNT_SAT;
+        if (cnt < FS_SLOT_CNT_SAT) pnd = atomicAdd(slot, 1u);
+        pend = pnd;
+        uint32_t w1_;                                                     // 1 iff prev == 0
+        asm("v_min_u32 %0, 1, %1" : "=v"(w1_) : "v"(prev));
+        n_won = w1_ ^ 1u;
+        res = cnt < prev ? cnt : prev;                                    // resolved iff matched, late or created
     }
-    if (!done) { overflow = true; rank = 0u; }
-    acc.nvox += is_new ? 1 : 0;                                       // occupied_voxel_count_++ (:304)
-    // crowding factor exp(1 - k^0.8) from the LDS copy (entry 0 and everything beyond rank ~340 are 0.0f).
-    // :318 — (float)(double information * float factor): the double product of two floats is exact, so one
-    // rounding to float == the fp32 product.
-    const float fac = lfac[rank < FS_FACTOR_N ? rank : FS_FACTOR_N - 1];
-    acc.info += (valid && rank != 0u) ? info_t * fac : 0.0f;
-    return is_new;
+    asm volatile("" : "+v"(res));     // (the compare stays out here, one instruction whose mask is the ballot)
+    const unsigned long long left_mask = __builtin_amdgcn_ballot_w64(res > FS_SLOT_CNT_MASK);
+    if (left_mask != 0ull) {
+        // ---- leftovers (a CAS lost to ANOTHER voxel, or a bucket with four other voxels), the general loop: it reads the
+        // bucket again and moves on to the next one when it is full
+        const bool left = __builtin_amdgcn_inverse_ballot_w64(left_mask);
+        bool done = !left;
+        pend = left ? 0xffffffffu : pend;
+        for (uint32_t probe = 1; probe < max_probe; ++probe) {
+            if (__all(done)) break;
+            if (!done) bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
+            const uint32_t w0 = bk.x, w1 = bk.y, w2 = bk.z, w3 = bk.w;
+            const uint32_t x0 = w0 ^ tag, x1 = w1 ^ tag, x2 = w2 ^ tag, x3 = w3 ^ tag;
+            const uint32_t xm3 = x0 < x1 ? (x0 < x2 ? x0 : x2) : (x1 < x2 ? x1 : x2);
+            const uint32_t xmin = xm3 < x3 ? xm3 : x3;
+            const bool has_match = xmin <= FS_SLOT_CNT_MASK;
+            const uint32_t jm = x0 == xmin ? 0u : (x1 == xmin ? 1u : (x2 == xmin ? 2u : 3u));
+            const uint32_t used = (w0 != 0u) + (w1 != 0u) + (w2 != 0u) + (w3 != 0u);
+            const bool can_insert = !has_match && used < 4u;
+            uint32_t *slot = table + (hb << 2) + (has_match ? jm : (used < 4u ? used : 0u));
+            uint32_t prev = 0xffffffffu;
+            if (!done && can_insert) prev = atomicCAS(slot, 0u, tag | 1u);
+            const bool won = !done && can_insert && prev == 0u;
+            const uint32_t xprev = prev ^ tag;
+            const bool late = !done && can_insert && prev != 0u && xprev <= FS_SLOT_CNT_MASK;
+            const bool do_add = !done && (has_match || late);
+            const uint32_t cnt = has_match ? xmin : xprev;
+            const bool sat = do_add && cnt >= FS_SLOT_CNT_SAT;
+            pend = won ? 0u : pend;
+            pend = sat ? FS_SLOT_CNT_SAT : pend;
+            if (do_add && !sat) pend = atomicAdd(slot, 1u);
+            n_won += won ? 1u : 0u;
+            const bool is_full = !done && !has_match && used >= 4u;
+            hb = is_full ? ((hb + 1u) & bmask) : hb;
+            done = done || won || do_add;
+        }
+        if (!done) { overflow = true; pend = 0xffffffffu; }
+    }
+    acc.nvox += (int)n_won;                                            // occupied_voxel_count_++ (:304)
+    acc.pend_old = pend;
+    acc.pend_info = info_t;                                           // (raw: a lane without a term has pend = ~0 -> factor 0.0f)
 }
 
 // wave64 sum with DPP row operations (no LDS traffic): the total lands in lane 63
@@ -305,20 +349,26 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // the previous candidate's scoring loop), and the chunk spheres a lane tests are the same for every candidate —
     // chunk (g * STRIDE + lane * WAVES + wave) for pass g — so the first four passes' spheres stay in registers for the
     // whole persistent loop: on clouds of up to 4 * THREADS chunks (C3: 1563) a cull issues no load at all.
-    struct PoseLoad { float4 r0, r1, r2; int status; uint32_t key; };   // key: the candidate's sort key (thread 0; cost map)
+    // ONE register per lane holds the record while it is in flight: lane k < 12 element k of (R row-major, t), lane 12 the
+    // status, lane 13 the sort key.  The cull broadcasts the elements with v_readlane (they are scalars there anyway); fourteen
+    // registers per lane for the same record were the difference between 128 VGPRs and a spill in the scoring loop.
+    struct PoseLoad { uint32_t v; };
     auto load_pose = [&](int c) -> PoseLoad {
         PoseLoad p;
         if (!FS_BOUND(c >= 0 && c < a.n, 6)) c = 0;
-        p.status = a.status ? a.status[c] : FS_STATUS_OK;
-        const float4 *rt = reinterpret_cast<const float4 *>(a.Rt + 12 * (size_t)c);
-        p.r0 = rt[0]; p.r1 = rt[1]; p.r2 = rt[2];
-        p.key = (!GLOBAL_TABLE && tid == 0 && a.costmap) ? a.cand_key[c] : 0u;     // requested here, used a whole candidate later
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.Rt + 12 * (size_t)c) + lane;
+        if (lane == 12) src = reinterpret_cast<const uint32_t *>(a.status) + (a.status ? c : 0);
+        if (lane == 13) src = (!GLOBAL_TABLE && a.costmap) ? a.cand_key + c : nullptr;
+        p.v = (lane < 14 && src) ? *src : 0u;                       // (status absent: 0 = FS_STATUS_OK)
         return p;
     };
+    auto pose_word = [&](const PoseLoad &pl, int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)pl.v, k); };
+    auto pose_elem = [&](const PoseLoad &pl, int k) -> float { return __builtin_bit_cast(float, pose_word(pl, k)); };
     constexpr bool RESIDENT_SPHERES = !GLOBAL_TABLE;              // (the 1024-thread HBM tier has no registers to spare)
-    float4 sp_res[4];
+    constexpr int N_RES = 4;                                      // passes whose spheres stay in registers
+    float4 sp_res[N_RES];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < N_RES; ++u) {
         const int j = u * STRIDE + lane * WAVES + wave;
         sp_res[u] = (RESIDENT_SPHERES && u < a.n_groups && j < a.n_chunks)
                         ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
@@ -326,14 +376,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     }
     auto cull = [&](const PoseLoad &pl, int buf, float *Rn, float *tn) {
         unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
-        const bool dead = pl.status != FS_STATUS_OK;
-        const float4 r0 = pl.r0, r1 = pl.r1, r2 = pl.r2;
-        Rn[0] = r0.x; Rn[1] = r0.y; Rn[2] = r0.z; Rn[3] = r0.w; Rn[4] = r1.x; Rn[5] = r1.y; Rn[6] = r1.z; Rn[7] = r1.w;
-        Rn[8] = r2.x; tn[0] = r2.y; tn[1] = r2.z; tn[2] = r2.w;
-        const float ax = r0.x, ay = r0.w, az = r1.z;               // the camera's +x axis in the world frame (R[0], R[3], R[6])
-        const float t0 = r2.y, t1 = r2.z, t2 = r2.w;
+        const bool dead = (int)pose_word(pl, 12) != FS_STATUS_OK;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rn[i] = pose_elem(pl, i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tn[i] = pose_elem(pl, 9 + i);
+        const float ax = Rn[0], ay = Rn[3], az = Rn[6];             // the camera's +x axis in the world frame (R[0], R[3], R[6])
+        const float t0 = tn[0], t1 = tn[1], t2 = tn[2];
         int tested = 0;
-        auto cull_one = [&](int j, const float4 s) -> bool {
+        auto cull_one = [&](int j, float4 s) -> bool {
             bool keep = j < a.n_chunks && !dead;
             if (keep && a.cull) {
                 const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;   // s.w carries a safety margin: conservative
@@ -355,8 +406,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             float4 sp[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int j = (gb + u) * STRIDE + lane * WAVES + wave;
-                if (RESIDENT_SPHERES && gb == 0) sp[u] = sp_res[u];
+                int j = (gb + u) * STRIDE + lane * WAVES + wave;
+                if (RESIDENT_SPHERES && gb == 0 && u < N_RES) sp[u] = sp_res[u < N_RES ? u : 0];
                 else sp[u] = (gb + u < a.n_groups && j < a.n_chunks)
                                  ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
                                  : make_float4(0.f, 0.f, 0.f, -1.f);
@@ -401,7 +452,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     for (int i = 0; i < 3; ++i) tn[i] = 0.f;
     if (cur >= 0) {
         if (GLOBAL_TABLE) first_pose = load_pose(cur);
-        cur_key = first_pose.key;
+        cur_key = pose_word(first_pose, 13);
         cull(first_pose, 0, Rn, tn);
     }
     __syncthreads();
@@ -463,13 +514,18 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         for (int i = 0; i < 9; ++i) R[i] = Rn[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) t[i] = tn[i];
+        // (vector registers on purpose: the test loop's multiply-adds with the pose as scalar operands measured 3 % slower)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(R[i]));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(t[i]));
         FS_STAMP(0);
         __syncthreads();                                           // table cleared
         FS_STAMP(1);
         const int nxt = __builtin_amdgcn_readfirstlane(sh_next[buf ^ 1]);
         PoseLoad next_pose;                                        // in flight during this candidate's scoring loop
         uint32_t next_key = 0u;
-        if (nxt >= 0) { next_pose = load_pose(nxt); next_key = next_pose.key; }
+        if (nxt >= 0) next_pose = load_pose(nxt);
         if (tid == 0) sh_overflow[buf ^ 1] = 0;                    // flag of the candidate after this one
         // (the flag is read and written with workgroup-scope atomics on the LDS array itself: a `volatile int *` into it
         // decays to a generic pointer, and FLAT accesses count on vmcnt — every read drained the landmark prefetch)
@@ -478,11 +534,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         bool overflow = false;
         if (skip_tier) { overflow = true; if (tid == 0) raise_overflow(); }
 
+        // (vector copies: a scalar operand turns a 2-cycle multiply or subtract into a 3-cycle one — tools/valu_mix_calib.hip)
+        float maxd2_v = a.maxd2, cos2_v = a.cos2;
+        asm volatile("" : "+v"(maxd2_v), "+v"(cos2_v));
         Acc acc;
         acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) acc.AB[i] = (fs_f2){0.f, 0.f};
         acc.s01 = (fs_f2){0.f, 0.f}; acc.s2 = 0.f;
+        acc.pend_old = 0xffffffffu; acc.pend_info = 0.f;
         int qcount = 0;                                            // wave-uniform
         const unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
 
@@ -496,27 +556,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             __syncthreads();
             if (stop) break;                                       // an earlier pass ran out of table: next tier
         }
-        // No barrier inside this loop: each wave walks its accepted chunks by iterating the ballot masks, with the
-        // next chunks' landmarks prefetched into registers while the current one is processed.
-        for (int g = 0; g < a.n_groups; ++g) {
-            const int g0 = g * STRIDE;
-            unsigned long long mask = masks[g];
-            mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
-                   ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
-            if (!GLOBAL_TABLE && __builtin_amdgcn_readfirstlane(overflow_flag())) break;   // another wave ran out of table: the HBM tier redoes it
-            auto pop = [&]() -> int {
-                if (!mask) return -1;
-                const int id = g0 + __builtin_ctzll(mask) * WAVES + wave;
-                mask &= mask - 1ull;
-                return id;
-            };
-            // (the prefetch is issued unconditionally — past the end of the mask it re-reads chunk 0 and the values are never
-            // used: no branch, no zeroing of three registers per iteration)
-            auto fetch = [&](int c, float &x, float &y, float &z) {
-                const int cc = (c >= 0 && FS_BOUND(c < a.n_chunks, 3)) ? c : 0;
-                const uint32_t l = (uint32_t)(cc * 64 + lane);
-                x = ldg32(LX, l); y = ldg32(LY, l); z = ldg32(LZ, l);
-            };
+        // No barrier inside this loop.  The wave turns its ballot masks into a FLAT LIST of accepted chunk ids held in one register
+        // (lane j = the j-th accepted chunk; compacted through 64 words of the wave's own queue that are free between two chunk
+        // tests) and walks it with v_readlane: drawing the next chunk costs one vector and three scalar instructions instead of
+        // the ten scalar ones of a find-first-bit walk, and the landmark prefetch no longer drains at every mask boundary.
+        // Scalar instructions are the expensive kind here: one costs a wave 8 cycles alone and 16 with four waves per SIMD
+        // (tools/valu_mix_calib.hip), more than any vector instruction of this loop.
+        {
+            uint32_t *scratch = reinterpret_cast<uint32_t *>(qz + 64);
+            const uint32_t my_chunk = (uint32_t)(lane * WAVES + wave);
             // One chunk's landmarks in registers: test, compact, and score whenever 64 are queued.
             auto body = [&](float wx, float wy, float wz) {
                 // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
@@ -525,14 +573,27 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
                 const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
                 const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
-                bool vis = (n2 <= a.maxd2);
                 float px2 = px * px;
                 asm("" : "+v"(px2));      // (keeps the compiler from pairing this product with cos2 * n2 in a v_pk_mul_f32 that needs two moves)
-                if (CONE1 || a.cone_mode == 1 || a.cone_mode == 3) vis = vis && (px >= 0.0f) && (px2 >= a.cos2 * n2);
-                else if (a.cone_mode == 2) vis = vis && ((px >= 0.0f) || (px2 <= a.cos2 * n2));
-                if (n_parts > 1) vis = vis && voxel_part(a, vis, px, n_parts) == part;   // wave-uniform branch
+                // The predicate is kept as ONE float whose sign decides (visible <=> m3 >= 0), so that the ballot below is the mask
+                // of a single compare — a boolean merged from several paths is materialised with a select and a second compare.
+                float m3;
+                if (CONE1) {
+                    // n2 <= maxd2 && px >= 0 && px2 >= cos2 * n2 in one value: the sign of a difference of two floats is exact, so each
+                    // condition is "its difference is >= 0" and the three are "their minimum is >= 0" (-0.0 passes, as px >= 0 does):
+                    // one v_min3_f32 and one compare instead of three compares and the scalar ANDs of their masks.
+                    const float c1 = maxd2_v - n2, c3 = px2 - cos2_v * n2;
+                    m3 = fminf(fminf(c1, px), c3);
+                } else {
+                    bool v = (n2 <= a.maxd2);
+                    if (a.cone_mode == 1 || a.cone_mode == 3) v = v && (px >= 0.0f) && (px2 >= a.cos2 * n2);
+                    else if (a.cone_mode == 2) v = v && ((px >= 0.0f) || (px2 <= a.cos2 * n2));
+                    m3 = v ? 0.0f : -1.0f;
+                }
+                if (n_parts > 1) m3 = (voxel_part(a, true, px, n_parts) == part) ? m3 : -1.0f;   // wave-uniform branch; every lane evaluates
+                const bool vis = m3 >= 0.0f;
                 // ---- 3. compact
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(vis);     // (the mask itself; __ballot goes through an integer compare)
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(vis);
                 if (m != 0ull) {
                     if (vis) {
                         const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -546,28 +607,50 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #ifdef FS_FIM_STAMPS
                         const unsigned long long ts_ = __builtin_readcyclecounter();
 #endif
-                        const bool opened = score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
+                        score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
 #ifdef FS_FIM_STAMPS
                         st[8] += __builtin_readcyclecounter() - ts_; st[9] += 1;
 #endif
-                        (void)opened;
                         if (__any(overflow)) raise_overflow();
                     }
                 }
             };
-            // Two register sets take turns (the loop is unrolled by two): while one chunk is tested the next one's landmarks
-            // arrive in the other set — no register rotation.
-            float xa, ya, za, xb, yb, zb;
-            int ca = pop();
-            fetch(ca, xa, ya, za);
-            while (ca >= 0) {
-                const int cb = pop();
-                fetch(cb, xb, yb, zb);
-                body(xa, ya, za);
-                if (cb < 0) break;
-                ca = pop();
-                fetch(ca, xa, ya, za);
-                body(xb, yb, zb);
+            int g = 0;
+            while (g < a.n_groups) {
+                if (!GLOBAL_TABLE && __builtin_amdgcn_readfirstlane(overflow_flag())) break;   // another wave ran out of table: the HBM tier redoes it
+                // ---- the next (up to) 64 accepted chunks: whole masks, as many as fit
+                int n_ids = 0;
+                do {
+                    unsigned long long mask = masks[g];
+                    mask = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask) |
+                           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mask >> 32)) << 32);   // wave-uniform copy
+                    const int cnt = __popcll(mask);
+                    if (n_ids + cnt > 64) break;                   // (never with n_ids == 0: a mask has 64 bits)
+                    if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+                        const int pos = n_ids + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                        scratch[pos] = (uint32_t)(g * STRIDE) + my_chunk;
+                    }
+                    n_ids += cnt;
+                    ++g;
+                } while (g < a.n_groups);
+                if (n_ids == 0) break;                             // (only when every remaining mask was empty)
+                const uint32_t ids = scratch[lane];                // lanes >= n_ids: stale words, never drawn
+                auto fetch = [&](int j, float &x, float &y, float &z) {
+                    const int c = __builtin_amdgcn_readlane((int)ids, j);
+                    const int cc = FS_BOUND(c >= 0 && c < a.n_chunks, 3) ? c : 0;
+                    const uint32_t l = (uint32_t)(cc * 64 + lane);
+                    x = ldg32(LX, l); y = ldg32(LY, l); z = ldg32(LZ, l);
+                };
+                // The next chunk's landmarks are in flight while the current one is tested; three cheap moves hand them over (one
+                // loop body, one inlined scoring call).  Past the end of the list the prefetch re-reads the last chunk (never used).
+                float nx_, ny_, nz_;
+                fetch(0, nx_, ny_, nz_);
+                const int last = n_ids - 1;
+                for (int j = 0; j <= last; ++j) {
+                    const float wx = nx_, wy = ny_, wz = nz_;
+                    fetch(min(j + 1, last), nx_, ny_, nz_);
+                    body(wx, wy, wz);
+                }
             }
         }
         FS_STAMP(2);
@@ -580,6 +663,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (overflow) raise_overflow();
         FS_STAMP(3);
         }   // passes
+        resolve_pending(acc, lfac);
 
         // ---- the next candidate's cull fills the time this wave would otherwise wait for the slower ones
         // The work item after the next one is drawn HERE, not at the top of the iteration: the device-scope atomic (a round trip
@@ -590,6 +674,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         unsigned long long ticket = 0ull;
         if (draw) ticket = atomicAdd(work.counter, 1ull);
         if (nxt >= 0) cull(next_pose, buf ^ 1, Rn, tn);
+        if (nxt >= 0) next_key = pose_word(next_pose, 13);
         if (tid == 0) sh_next[buf] = draw ? item((int)ticket + preassigned) : -1;   // read by the next iteration after its first barrier
 
         FS_STAMP(4);
@@ -615,7 +700,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         const bool failed = __builtin_amdgcn_readfirstlane(sh_overflow[buf]) != 0;
         // (the sums by the first lanes of wave 1, the flags and counters below by thread 0: the two halves of the epilogue run side
         // by side instead of one after the other on wave 0, which everybody waits for at the next barrier)
-        const int qi = tid - (WAVES > 1 ? 64 : 0);
+        int qi = tid - (WAVES > 1 ? 64 : 0);
         if (qi >= 0 && qi < FS_NACC && !failed) {
             float part[WAVES];
 #pragma unroll

@@ -35,6 +35,8 @@ SQ_PASSES = {
     "cycles": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS"],
     "stalls": ["SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_SALU", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_MISC", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_THREAD_CYCLES_VALU", "SQ_INST_CYCLES_VMEM"],
     "grbm": ["GRBM_GUI_ACTIVE", "GRBM_COUNT"],
+    # in-flight instruction levels: LEVEL / INSTS = the average latency of a vector-memory / LDS instruction in cycles
+    "levels": ["SQ_INST_LEVEL_VMEM", "SQ_INSTS_VMEM", "SQ_INST_LEVEL_LDS", "SQ_INSTS_LDS", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_ATOMIC_RETURN", "SQ_INSTS_LDS_ATOMIC", "SQ_WAVE_CYCLES"],
     "fetch": ["FETCH_SIZE"],
     "write": ["WRITE_SIZE"],
     "tcc": ["TCC_HIT_sum", "TCC_MISS_sum"],
