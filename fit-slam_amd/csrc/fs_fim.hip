@@ -485,19 +485,26 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // candidate) or a hand-over to a second kernel with a larger LDS table (round 1: a 0.18 ms serial tail on C3).
         // Prediction: distinct voxels <= skip32/32 of the landmarks scanned (measured p99 0.40 on C3; 13/32 by default);
         // a candidate that overflows a pass all the same is handed to the HBM tier — correct, just slower.
-        const long long capacity = 3ll << (tier_bits - 2);                           // 3/4 of the largest table
+        // (closed forms: written as loops the compiler unrolled and vectorised these few scalar steps into eighty instructions per
+        // candidate and wave)
+        const uint32_t capacity = 3u << (tier_bits - 2);                             // 3/4 of the largest table
         int n_parts = 1;
         bool skip_tier = false;
         if (!GLOBAL_TABLE) {
-            const long long predicted = (long long)wg_tested * 2 * a.skip32;           // = landmarks scanned * skip32 / 32
-            while (n_parts <= FS_MAX_PARTS && predicted > capacity * n_parts) n_parts <<= 1;
-            skip_tier = n_parts > FS_MAX_PARTS;                                       // hopeless here: HBM tier
+            // = landmarks scanned * skip32 / 32, in 32 bits (beyond 2^20 accepted chunks the answer is the HBM tier anyway)
+            const uint32_t scanned2 = (uint32_t)(wg_tested < (1 << 20) ? wg_tested : (1 << 20)) * 2u;
+            const uint32_t predicted = scanned2 * (uint32_t)a.skip32;
+            const int k = (predicted > capacity ? 1 : 0) + (predicted > 2u * capacity ? 1 : 0) + (predicted > 4u * capacity ? 1 : 0) +
+                          (predicted > 8u * capacity ? 1 : 0);
+            n_parts = 1 << k;                                                         // 1, 2, 4, 8 passes
+            skip_tier = n_parts > FS_MAX_PARTS;                                       // 16: hopeless here, HBM tier
         }
         int bits = tier_bits;
         if (!GLOBAL_TABLE && n_parts == 1) {
-            int need = 10;
-            while (need < tier_bits && (1 << need) < wg_tested * 64) ++need;
-            bits = need;
+            // smallest table with at least as many slots as landmarks scanned, between 2^10 and the tier's size
+            const uint32_t want = (uint32_t)wg_tested * 64u;     // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
+            const int need = want > 1024u ? 32 - __builtin_clz(want - 1u) : 10;
+            bits = need < tier_bits ? need : tier_bits;
         }
         const uint32_t slots = 1u << bits;
         if (!skip_tier && wg_tested > 0) {
