@@ -490,6 +490,7 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     a.table_full = c->table_full ? 1 : 0;
     a.maxd2 = (float)(c->fp.max_dist * c->fp.max_dist);
     a.max_dist_f = (float)c->fp.max_dist * 1.0001f + 1.0e-3f;      // culling reach, rounded outwards
+    a.far_lattice = !((double)a.max_dist_f * a.inv_step < 1000.0) ? 1 : 0;   // (NaN / inf / huge ranges: exact path for every landmark)
     if (c->fp.max_angle >= M_PI) {
         a.cone_mode = 0; a.cos2 = 0.0f; a.cos_a = -1.0f; a.sin_a = 0.0f;
     } else {
