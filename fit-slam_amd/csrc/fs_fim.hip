@@ -265,19 +265,31 @@ __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *tabl
     acc.pend_info = info_t;                                           // (raw: a lane without a term has pend = ~0 -> factor 0.0f)
 }
 
-// wave64 sum with DPP row operations (no LDS traffic): the total lands in lane 63
-__device__ __forceinline__ float wave_sum_dpp(float v)
+// wave64 sums with DPP row operations (no LDS traffic): the totals land in lane 63.  N values at once, step by step: the two
+// cross-row steps are written as ONE v_add_f32_dpp each with a partial row mask (rows outside the mask keep their value) —
+// from the builtin the compiler makes a move of the identity, a DPP move and an add — and an instruction that reads a register
+// through DPP must be two instructions behind the one that wrote it, which the step-major order provides (the assembler does
+// not look into inline asm: hence the one s_nop in front of the first).
+template <int N>
+__device__ __forceinline__ void wave_sums_dpp(float (&v)[N])
 {
-#define FS_DPP_ADD(ctrl, rmask)                                                                              \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, true))
-    FS_DPP_ADD(0x111, 0xf);   // row_shr:1
-    FS_DPP_ADD(0x112, 0xf);   // row_shr:2
-    FS_DPP_ADD(0x114, 0xf);   // row_shr:4
-    FS_DPP_ADD(0x118, 0xf);   // row_shr:8   -> lane 15 of each row holds the row sum
-    FS_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
-    FS_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    static_assert(N >= 3, "the step-major order is what separates a DPP read from the write before it");
+#define FS_DPP_ADD(x, ctrl)                                                                                   \
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+#pragma unroll
+    for (int i = 0; i < N; ++i) FS_DPP_ADD(v[i], 0x111);   // row_shr:1
+#pragma unroll
+    for (int i = 0; i < N; ++i) FS_DPP_ADD(v[i], 0x112);   // row_shr:2
+#pragma unroll
+    for (int i = 0; i < N; ++i) FS_DPP_ADD(v[i], 0x114);   // row_shr:4
+#pragma unroll
+    for (int i = 0; i < N; ++i) FS_DPP_ADD(v[i], 0x118);   // row_shr:8   -> lane 15 of each row holds the row sum
 #undef FS_DPP_ADD
-    return v;
+    asm volatile("s_nop 1");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v[i]));   // into rows 1 and 3
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v[i]));   // into rows 2 and 3 -> lane 63
 }
 
 // dynamic-LDS carve-up of one workgroup: [per-wave compaction queues][factor copy][chunk masks][hash table]
@@ -694,8 +706,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         vals[13] = acc.s01.x; vals[14] = acc.s01.y; vals[15] = acc.s2;
         vals[16] = (float)acc.nvis;     // exact: < 2^24 per lane
         vals[17] = (float)acc.nvox;
-#pragma unroll
-        for (int i = 0; i < FS_NACC; ++i) vals[i] = wave_sum_dpp(vals[i]);
+        wave_sums_dpp(vals);
         if (lane == 63) {
 #pragma unroll
             for (int i = 0; i < FS_NACC; ++i) sh_red[i * WAVES + wave] = vals[i];     // [quantity][wave]: one thread reads its row with wide loads
