@@ -385,7 +385,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         const int j = u * STRIDE + lane * WAVES + wave;
         sp_res[u] = (RESIDENT_SPHERES && u < a.n_groups && j < a.n_chunks)
                         ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
-                        : make_float4(0.f, 0.f, 0.f, -1.f);
+                        : make_float4(0.f, 0.f, 0.f, -1.0e30f);
     }
     auto cull = [&](const PoseLoad &pl, int buf, float *Rn, float *tn) {
         unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
@@ -397,23 +397,27 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         const float ax = Rn[0], ay = Rn[3], az = Rn[6];             // the camera's +x axis in the world frame (R[0], R[3], R[6])
         const float t0 = tn[0], t1 = tn[1], t2 = tn[2];
         int tested = 0;
-        auto cull_one = [&](int j, float4 s) -> bool {
-            bool keep = j < a.n_chunks && !dead;
-            if (keep && a.cull) {
-                const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;   // s.w carries a safety margin: conservative
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                const float reach = a.max_dist_f + s.w;
-                keep = reach >= 0.0f && d2 <= reach * reach;         // empty chunks carry a hugely negative radius
-                if (keep && (CONE1 || a.cone_mode == 1) && d2 > s.w * s.w) {
-                    // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
-                    // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one
-                    // hardware square root; the margin dwarfs its 1-ulp error)
-                    const float h = __builtin_amdgcn_sqrtf(d2 - s.w * s.w);
-                    const float dot = dx * ax + dy * ay + dz * az;
-                    keep = dot >= a.cos_a * h - a.sin_a * s.w - (1.0e-4f * reach + 1.0e-4f);     // |d| <= reach here
-                }
+        // One sphere against the visibility volume, conservatively (s.w carries a safety margin), as the sign of ONE value: every
+        // condition is "a difference is >= 0" (exact in floating point), AND is a minimum, OR a maximum — straight-line code, no
+        // exec-mask nesting (three levels of it and their scalar bookkeeping in the branchy version).  A lane without a chunk
+        // holds a sphere of radius -1e30: its reach is negative.
+        const unsigned long long live = dead ? 0ull : ~0ull;
+        auto cull_one = [&](int j, const float4 s) -> bool {
+            if (!a.cull) return j < a.n_chunks;                       // brute force (wave-uniform)
+            const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const float reach = a.max_dist_f + s.w, r2 = s.w * s.w;
+            float c = fminf(reach, reach * reach - d2);               // within reach of the range sphere
+            if (CONE1 || a.cone_mode == 1) {
+                // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
+                // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one hardware
+                // square root; the margin dwarfs its 1-ulp error) — or the camera sits inside the sphere (|d|^2 <= r^2)
+                const float h = __builtin_amdgcn_sqrtf(fmaxf(d2 - r2, 0.0f));
+                const float dot = dx * ax + dy * ay + dz * az;
+                const float lhs = dot - (a.cos_a * h - a.sin_a * s.w - (1.0e-4f * reach + 1.0e-4f));     // |d| <= reach here
+                c = fminf(c, fmaxf(lhs, r2 - d2));
             }
-            return keep;
+            return c >= 0.0f;
         };
         for (int gb = 0; gb < a.n_groups; gb += 4) {
             float4 sp[4];
@@ -423,13 +427,13 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 if (RESIDENT_SPHERES && gb == 0 && u < N_RES) sp[u] = sp_res[u < N_RES ? u : 0];
                 else sp[u] = (gb + u < a.n_groups && j < a.n_chunks)
                                  ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
-                                 : make_float4(0.f, 0.f, 0.f, -1.f);
+                                 : make_float4(0.f, 0.f, 0.f, -1.0e30f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (gb + u < a.n_groups) {
                     const int j = (gb + u) * STRIDE + lane * WAVES + wave;
-                    const unsigned long long mask = __ballot(cull_one(j, sp[u]));
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(cull_one(j, sp[u])) & live;
                     tested += __popcll(mask);
                     if (lane == 0) masks[gb + u] = mask;
                 }
