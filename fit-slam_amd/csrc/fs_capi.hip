@@ -361,7 +361,7 @@ int build_dense(fs_ctx *c)
         c->dense[idx] = c->records[4 * i + 3];
     }
     c->table_full = true;
-    for (float v : c->dense) if (std::isnan(v)) { c->table_full = false; break; }
+    for (float v : c->dense) if (!std::isfinite(v)) { c->table_full = false; break; }   // (NaN = absent; an infinite value also takes the guarded kernel)
     FS_HIP(c, c->d_table.ensure(c->dense.size()));
     FS_HIP(c, hipMemcpyAsync(c->d_table.p, c->dense.data(), c->dense.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (!c->have_factor) {

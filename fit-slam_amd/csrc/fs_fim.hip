@@ -74,11 +74,15 @@ struct Acc {
     uint32_t pend_old; float pend_info;
 };
 
+// (rank = count + 1; ~0 -> the factor table's last entry, which is 0.0f.  With a table of finite values only — TABLE_FULL — a lane
+// without a term may simply add value * 0.0f; a NaN hole must not reach the product.)
+template <bool TABLE_FULL>
 __device__ __forceinline__ void resolve_pending(Acc &acc, const float *lfac)
 {
-    const uint32_t rank = (acc.pend_old & FS_SLOT_CNT_MASK) + 1u;           // 0xffffffff -> 2048 -> the table's last entry: 0.0f
-    const float fac = lfac[rank < FS_FACTOR_N ? rank : FS_FACTOR_N - 1];
-    acc.info += fac > 0.0f ? acc.pend_info * fac : 0.0f;
+    const uint32_t cnt = acc.pend_old & FS_SLOT_CNT_MASK;
+    const float fac = (lfac + 1)[cnt < FS_FACTOR_N - 2 ? cnt : FS_FACTOR_N - 2];
+    if (TABLE_FULL) acc.info += acc.pend_info * fac;
+    else acc.info += fac > 0.0f ? acc.pend_info * fac : 0.0f;
 }
 
 // base[idx] with a 32-bit BYTE offset: lets the load use the scalar-base + 32-bit vector-offset addressing form instead
@@ -166,7 +170,7 @@ __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *tabl
     (void)FS_BOUND(hb <= bmask, 5);
     hb &= bmask;      // whatever the hash returns, the bucket index stays inside the table
     uint4 bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
-    resolve_pending(acc, lfac);                                       // the previous call's landmarks
+    resolve_pending<TABLE_FULL>(acc, lfac);                           // the previous call's landmarks
     {
         const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
         const float q = (active && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f;
@@ -687,7 +691,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (overflow) raise_overflow();
         FS_STAMP(3);
         }   // passes
-        resolve_pending(acc, lfac);
+        resolve_pending<TABLE_FULL>(acc, lfac);
 
         // ---- the next candidate's cull fills the time this wave would otherwise wait for the slower ones
         // The work item after the next one is drawn HERE, not at the top of the iteration: the device-scope atomic (a round trip

@@ -136,7 +136,7 @@ struct FsFimArgs {
     int32_t far_lattice;       // 1: max_dist / step may reach 2^10 lattice cells — the fp32 fast path of the voxel index is not proven there
     const float *factor;       // crowding factor by rank, [FS_FACTOR_N]; rank >= FS_FACTOR_N -> 0
     float fac1, fac2, fac3, fac4;   // factor[1..4]
-    int32_t table_full;        // 1: no NaN inside the table box (true for every generated table)
+    int32_t table_full;        // 1: only finite values inside the table box (true for every generated table)
     // visibility
     float maxd2;               // (float)(max_dist^2)
     float cos2;                // c*c, c = (float)cos(max_angle)
