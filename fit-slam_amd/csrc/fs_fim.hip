@@ -197,8 +197,8 @@ __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *tabl
         // the two lowest bits of the difference — the match test looks at bits >= 11, saturation at bit 10, the exact count
         // comes back from the add — so the smallest of the four is the match AND says where it sits: no compare / select chain.
         const uint32_t y0 = (w0 ^ tag) & ~3u, y1 = ((w1 ^ tag) & ~3u) | 1u, y2 = ((w2 ^ tag) & ~3u) | 2u, y3 = ((w3 ^ tag) & ~3u) | 3u;
-        const uint32_t ym3 = y0 < y1 ? (y0 < y2 ? y0 : y2) : (y1 < y2 ? y1 : y2);                       // v_min3_u32
-        const uint32_t ymin = ym3 < y3 ? ym3 : y3;
+        const uint32_t y01 = y0 < y1 ? y0 : y1, y23 = y2 < y3 ? y2 : y3;                                // v_min_u32, v_min3_u32
+        const uint32_t ymin = y01 < y23 ? y01 : y23;
         const bool has_match = ymin <= FS_SLOT_CNT_MASK;
         // slots fill in order: the first empty one is the number of occupied ones
         uint32_t u0, u1, u2, u3;
