@@ -81,12 +81,14 @@ struct WalkLinear {
 // axis — and a cell arrives as its class (bit 0: in the trace range, bit 1: in the obstacle range), so the visitor is two
 // bit tests.  More instructions per step than WalkLinear, 4-8x fewer cache lines per ray.
 struct WalkClass {
-    uint32_t a, b, c;        // cell coordinates along the major and the two minor axes
-    int sga, sgb, sgc;       // sign(d) with sign(0) = -1 (Helpers.hpp:113-116)
+    // cell coordinates along the major and the two minor axes, each PRE-SHIFTED by its axis' position inside a brick (x: 0, y: 3,
+    // z: 6 bits): coordinate << s is the axis' share of the in-brick address, so the address needs no multiply for it
+    uint32_t a, b, c;
+    int sga, sgb, sgc;       // sign(d) with sign(0) = -1 (Helpers.hpp:113-116), shifted likewise: what a step adds
     uint32_t abs_da, adb, adc;
     int eb, ec;
-    uint32_t la, lb, lc;     // 1 / 8 / 64: the cell stride of the axis inside a brick (x / y / z)
-    uint32_t ma, mb, mc;     // FsGridDev::cls_m[axis]: brick stride of the axis minus (8 << l)
+    uint32_t ha, hb, hc;     // s + 3: (coordinate << s) >> (s + 3) = the axis' brick index
+    uint32_t ma, mb, mc;     // FsGridDev::cls_m[axis]: brick stride of the axis minus (8 << s)
     uint32_t end;
 };
 
@@ -137,13 +139,12 @@ __device__ __forceinline__ uint32_t walk_class(const FsGridDev &g, const WalkCla
 {
     // (24-bit multiplies run at full rate, 32-bit ones at a quarter of it; brick indices and strides are far below 2^24 —
     // fs_capi.hip only selects this walk where they are)
-    // one multiply-add chain: v * (1 << l) + (v >> 3) * m per axis
-    uint32_t A = (uint32_t)__umul24(w.c >> 3, w.mc);
-    A = (uint32_t)__umul24(w.c, w.lc) + A;
-    A = (uint32_t)__umul24(w.b >> 3, w.mb) + A;
-    A = (uint32_t)__umul24(w.b, w.lb) + A;
-    A = (uint32_t)__umul24(w.a >> 3, w.ma) + A;
-    A = (uint32_t)__umul24(w.a, w.la) + A;
+    // v * (1 << s) + (v >> 3) * m per axis: the first terms are the pre-shifted coordinates themselves (one three-operand add),
+    // the second three shifts and three multiply-adds — seven instructions where products of the unshifted coordinates took eleven
+    uint32_t A = w.a + w.b + w.c;
+    A = (uint32_t)__umul24(w.c >> w.hc, w.mc) + A;
+    A = (uint32_t)__umul24(w.b >> w.hb, w.mb) + A;
+    A = (uint32_t)__umul24(w.a >> w.ha, w.ma) + A;
 #ifdef FS_RAY_BOUNDS
     if (A >= g.cls_cells) { atomicMax(g.dbg, 6ull); return 0u; }
 #endif
@@ -207,14 +208,14 @@ __device__ __forceinline__ void walk_init(WalkClass &w, const FsGridDev &g, uint
     const int sx = sign_ref(dx), sy = sign_ref(dy), sz = sign_ref(dz);
     // the axis order of walk_init(WalkLinear): the first largest extent is the major axis
     if (adx >= ady && adx >= adz) {
-        w.a = x0; w.b = y0; w.c = z0; w.sga = sx; w.sgb = sy; w.sgc = sz; w.abs_da = adx; w.adb = ady; w.adc = adz;
-        w.la = 1; w.lb = 8; w.lc = 64; w.ma = g.cls_m[0]; w.mb = g.cls_m[1]; w.mc = g.cls_m[2];
+        w.a = x0; w.b = y0 << 3; w.c = z0 << 6; w.sga = sx; w.sgb = sy * 8; w.sgc = sz * 64; w.abs_da = adx; w.adb = ady; w.adc = adz;
+        w.ha = 3; w.hb = 6; w.hc = 9; w.ma = g.cls_m[0]; w.mb = g.cls_m[1]; w.mc = g.cls_m[2];
     } else if (ady >= adz) {
-        w.a = y0; w.b = x0; w.c = z0; w.sga = sy; w.sgb = sx; w.sgc = sz; w.abs_da = ady; w.adb = adx; w.adc = adz;
-        w.la = 8; w.lb = 1; w.lc = 64; w.ma = g.cls_m[1]; w.mb = g.cls_m[0]; w.mc = g.cls_m[2];
+        w.a = y0 << 3; w.b = x0; w.c = z0 << 6; w.sga = sy * 8; w.sgb = sx; w.sgc = sz * 64; w.abs_da = ady; w.adb = adx; w.adc = adz;
+        w.ha = 6; w.hb = 3; w.hc = 9; w.ma = g.cls_m[1]; w.mb = g.cls_m[0]; w.mc = g.cls_m[2];
     } else {
-        w.a = z0; w.b = x0; w.c = y0; w.sga = sz; w.sgb = sx; w.sgc = sy; w.abs_da = adz; w.adb = adx; w.adc = ady;
-        w.la = 64; w.lb = 1; w.lc = 8; w.ma = g.cls_m[2]; w.mb = g.cls_m[0]; w.mc = g.cls_m[1];
+        w.a = z0 << 6; w.b = x0; w.c = y0 << 3; w.sga = sz * 64; w.sgb = sx; w.sgc = sy * 8; w.abs_da = adz; w.adb = adx; w.adc = ady;
+        w.ha = 9; w.hb = 3; w.hc = 6; w.ma = g.cls_m[2]; w.mb = g.cls_m[0]; w.mc = g.cls_m[1];
     }
     w.eb = w.ec = (int)(w.abs_da / 2);
     w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
