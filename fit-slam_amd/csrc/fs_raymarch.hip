@@ -92,16 +92,7 @@ struct WalkClass {
     uint32_t end;
 };
 
-__device__ __forceinline__ void walk_step(WalkLinear &w)
-{
-    w.offset += (uint32_t)w.off_a;
-    w.err_b += (int)w.abs_db;
-    if ((uint32_t)w.err_b >= w.abs_da) { w.offset += (uint32_t)w.off_b; w.err_b -= (int)w.abs_da; }
-    w.err_c += (int)w.abs_dc;
-    if ((uint32_t)w.err_c >= w.abs_da) { w.offset += (uint32_t)w.off_c; w.err_c -= (int)w.abs_da; }
-}
-
-// one minor axis of the class walk: e += |d_minor|; if (e >= |d_major|) { v += sign; e -= |d_major|; } in five instructions —
+// one minor axis of a walk: e += |d_minor|; if (e >= |d_major|) { v += sign; e -= |d_major|; } in five instructions —
 // the subtraction's borrow IS the comparison (v_sub_co_u32), the smaller of e and e - |d_major| (unsigned wrap) is the new
 // error term.  (The compiler spends a sixth on a separate compare.)
 __device__ __forceinline__ void minor_step(uint32_t &v, int &e, uint32_t ad, uint32_t da, int sg)
@@ -115,6 +106,13 @@ __device__ __forceinline__ void minor_step(uint32_t &v, int &e, uint32_t ad, uin
         : [e] "+v"(e), [v] "+v"(v), [t] "=&v"(t)
         : [ad] "v"(ad), [da] "v"(da), [sg] "v"(sg)
         : "vcc");
+}
+
+__device__ __forceinline__ void walk_step(WalkLinear &w)
+{
+    w.offset += (uint32_t)w.off_a;
+    minor_step(w.offset, w.err_b, w.abs_db, w.abs_da, w.off_b);
+    minor_step(w.offset, w.err_c, w.abs_dc, w.abs_da, w.off_c);
 }
 
 __device__ __forceinline__ void walk_step(WalkClass &w)
