@@ -139,6 +139,24 @@ def test_fim_known_answers(scorer):
     assert abs(r["info_ref"][0] - 2.854701 * S5) < 2e-4
 
 
+def test_fim_voxel_count_saturates(fs, oracle, scorer, ref_table):
+    """3 000 landmarks in ONE voxel (and 1 500 in a second): the slot's 11-bit count field stops at FS_SLOT_CNT_SAT = 1024 —
+    beyond rank 337 the factor exp(1 - k^0.8) is 0.0f in float32 anyway — and must neither run over into the key bits nor
+    open a second entry for the voxel."""
+    rng = np.random.default_rng(17)
+    a = np.array([1.2, -0.9, 0.3]) + rng.uniform(-0.05, 0.05, size=(3000, 3))
+    b = np.array([3.0, 0.3, -0.6]) + rng.uniform(-0.05, 0.05, size=(1500, 3))
+    lm = np.concatenate([a, b]).astype(np.float32)
+    rng.shuffle(lm)
+    pose = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
+    scorer.upload_landmarks(lm)
+    scorer.set_fim_params(14.0, 1.3)
+    got = scorer.score_fim(pose)
+    want = oracle.pose_information(ref_table, lm, pose, 14.0, 1.3, n_threads=1)
+    assert got["n_visible"][0] == 4500 and got["n_voxels"][0] == 2
+    _check_fim(got, want, lm.shape[0])
+
+
 def _check_fim(got, want, n_lm):
     np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
     np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
