@@ -245,15 +245,22 @@ def main():
         hbm = summary.get("fs_fim_kernel_hbm_bytes_per_launch")
         dur = res.get("duration_us")
         if u is not None and w_any is not None:
+            # (the label only names what the figures below show; DESIGN.md 4.2 has the argument: at four waves per SIMD the
+            # kernel's time follows its instruction count by kind — the waits a wave sees are covered by the CU's other workgroup)
+            u4 = res.get("valu_issue_utilisation_vs_4_wave_peak")
             if u >= 0.75:
                 summary["bound"] = "valu-issue"
+            elif u4 is not None and u4 >= 0.5:
+                summary["bound"] = "instruction issue at 4 waves per SIMD"
             elif w_any + (w_inst or 0.0) >= 0.5:
-                summary["bound"] = "latency"      # waves parked on LDS-atomic / barrier / load waits at 4 waves per SIMD
+                summary["bound"] = "latency"      # waves parked on LDS-atomic / barrier / load waits
             else:
                 summary["bound"] = "mixed"
             summary["bound_evidence"] = (
                 f"fs_fim_kernel: VALU issue {u:.0%} of the SIMD peak measured by tools/valu_calib "
-                f"({summary['valu_peak_wave_insts_per_cycle_per_simd']:.3f} wave-insts/cycle/SIMD), waves parked {w_any:.0%} "
+                f"({summary['valu_peak_wave_insts_per_cycle_per_simd']:.3f} wave-insts/cycle/SIMD)"
+                + (f", {u4:.0%} of what four waves of independent v_fma_f32 reach" if u4 is not None else "")
+                + f", waves parked {w_any:.0%} "
                 f"(SQ_WAIT_ANY) + issue-stalled {(w_inst or 0.0):.0%} (SQ_WAIT_INST_ANY) of their cycles"
                 + (f", L2 hit rate {res['l2_hit_rate']:.1%}" if "l2_hit_rate" in res else "")
                 + (f", HBM traffic {hbm / 1e6:.1f} MB per launch = {hbm / (dur * 1e-6) / 1e9:.0f} GB/s of 8000" if hbm and dur else "")
