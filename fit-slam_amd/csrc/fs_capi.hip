@@ -1051,12 +1051,12 @@ int fs_trace_segments(fs_ctx *c, int32_t n, const double *start_xyz, const doubl
 
 // ------------------------------------------------------------------ Fisher information
 
-int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
+}  // extern "C"
+
+// Host half of fs_upload_landmarks: the cloud in k-d leaf order as SoA + one bounding sphere per chunk.  A function of the
+// input alone — fs_multi runs it once and hands the result to every device.
+void fs_stage_landmarks(const float *xyz, int32_t m, FsStagedCloud &out)
 {
-    if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
-    FS_HIP(c, hipSetDevice(c->device));
-    // chunk masks live in LDS (one bit per chunk) next to the 64-KiB tier-1 table
-    if (m > 2000000) return fail(c, FS_E_INVALID, "at most 2,000,000 landmarks per context");
     // Chunks of 64 consecutive landmarks are the unit of visibility culling, so the cloud is put into the leaf order
     // of a k-d tree with exactly 64 landmarks per leaf: split the longest axis of the bounding box at the multiple of
     // 64 nearest the median, left part first; a remainder always goes right and ends up as the last, short chunk.
@@ -1102,7 +1102,8 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
     const int32_t n_chunks = std::max<int32_t>(1, (m + FS_CHUNK - 1) / FS_CHUNK);
     const size_t mp = (size_t)n_chunks * FS_CHUNK;
     // SoA + far-away sentinels in the padding: (1e18)^2 is finite in fp32 and beyond any max_dist^2
-    std::vector<float> x(mp, 1.0e18f), y(mp, 1.0e18f), z(mp, 1.0e18f), sph((size_t)n_chunks * 4, 0.0f);
+    std::vector<float> &x = out.x, &y = out.y, &z = out.z, &sph = out.sph;
+    x.assign(mp, 1.0e18f); y.assign(mp, 1.0e18f); z.assign(mp, 1.0e18f); sph.assign((size_t)n_chunks * 4, 0.0f);
     for (int32_t i = 0; i < m; ++i) {
         const float *p = xyz + 3 * (size_t)order[i];
         x[i] = p[0]; y[i] = p[1]; z[i] = p[2];
@@ -1130,6 +1131,17 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
         s4[0] = ctr[0]; s4[1] = ctr[1]; s4[2] = ctr[2];
         s4[3] = (float)(std::sqrt(r2) * 1.01 + 2.0e-3);          // safety margin: culling must never drop a visible landmark
     }
+    out.m = m; out.n_chunks = n_chunks;
+}
+
+// Device half: four copies and the HBM-tier tables.
+int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    const int32_t m = st.m, n_chunks = st.n_chunks;
+    const size_t mp = (size_t)n_chunks * FS_CHUNK;
+    const std::vector<float> &x = st.x, &y = st.y, &z = st.z, &sph = st.sph;
     FS_HIP(c, c->d_lx.ensure(mp)); FS_HIP(c, c->d_ly.ensure(mp)); FS_HIP(c, c->d_lz.ensure(mp));
     FS_HIP(c, c->d_spheres.ensure(sph.size()));
     FS_HIP(c, hipMemcpyAsync(c->d_lx.p, x.data(), sizeof(float) * mp, hipMemcpyHostToDevice, c->stream));
@@ -1145,6 +1157,18 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
     FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
     c->have_lm = true;
     return FS_OK;
+}
+
+extern "C" {
+
+int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
+{
+    if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
+    // chunk masks live in LDS (one bit per chunk) next to the 64-KiB tier-1 table
+    if (m > 2000000) return fail(c, FS_E_INVALID, "at most 2,000,000 landmarks per context");
+    FsStagedCloud st;
+    fs_stage_landmarks(xyz, m, st);
+    return fs_upload_staged_landmarks(c, st);
 }
 
 int fs_set_option(fs_ctx *c, const char *key, double value)

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/fitslam_frontier.h"
 #include "../../include/fitslam_frontier_dev.h"
 
@@ -117,6 +119,15 @@ struct FsKfArgs {
     int32_t gbits;
 };
 hipError_t fs_launch_kf_info(const FsKfArgs &a, int pool, hipStream_t s);
+
+// ---- landmark staging (fs_capi.hip), split so that fs_multi orders a cloud once for all its devices
+struct FsStagedCloud {
+    int32_t m = 0, n_chunks = 0;
+    std::vector<float> x, y, z;     // SoA in k-d leaf order, padded to whole chunks with far-away sentinels
+    std::vector<float> sph;         // [n_chunks][4] bounding spheres (cx, cy, cz, r + safety margin)
+};
+void fs_stage_landmarks(const float *xyz, int32_t m, FsStagedCloud &out);
+int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st);
 
 // ---- FIM kernel arguments ---------------------------------------------------------------------
 struct FsFimArgs {
