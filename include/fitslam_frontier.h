@@ -291,7 +291,9 @@ fs_ctx *fs_multi_ctx(fs_multi *m, int i);                  /* member context i (
 const char *fs_multi_last_error(const fs_multi *m);
 /* block [*lo, *hi) of shard `shard` of `n_shards` over a list of n: lo = min(n, shard * ceil(n / n_shards)), hi = min(n, lo + ceil(n / n_shards)) */
 int  fs_multi_shard_bounds(int32_t n, int n_shards, int shard, int32_t *lo, int32_t *hi);
-/* each of these applies the fs_* call of the same name to every member (first failure is returned) */
+/* each of these applies the fs_* call of the same name to every member (first failure is returned).  The two uploads reach
+   all devices at the same time (one short-lived host thread per member; the cloud is k-d ordered once for all of them);
+   the caller sees one blocking call. */
 int  fs_multi_set_option(fs_multi *m, const char *key, double value);
 int  fs_multi_set_ray_params(fs_multi *m, const fs_ray_params *p);
 int  fs_multi_upload_grid(fs_multi *m, const uint8_t *cells, int32_t nx, int32_t ny, int32_t nz, const double origin_xyz[3], double resolution);
