@@ -331,10 +331,18 @@ void generate_records(float minX, float maxX, float minY, float maxY, float minZ
     rec.insert(rec.end(), {0.0f, 0.0f, 0.0f, max_fi});
 }
 
+// The FIM worker's pass prediction learns the cloud's voxels-per-landmark ratio from finished calls (counters[12], fs_fim.hip);
+// what it learnt holds for one cloud, one table and one visibility volume.
+static void reset_voxel_ratio(fs_ctx *c)
+{
+    if (c->d_counters.p) (void)hipMemsetAsync(c->d_counters.p + 12, 0, sizeof(unsigned long long), c->stream);
+}
+
 // Dense re-indexing of the record list by the integer voxel lattice (what loadLookupTable's
 // unordered_map resolves to: later duplicates overwrite, FisherInfoManager.cpp:245-251).
 int build_dense(fs_ctx *c)
 {
+    reset_voxel_ratio(c);
     const int64_t n = (int64_t)c->records.size() / 4;
     if (n <= 0) return fail(c, FS_E_INVALID, "lookup table has no records");
     const double step = (double)kStepMax, inv = 1 / step;
@@ -396,7 +404,7 @@ void pose_to_rt(const double pose7[7], float Rt[12])
 
 // Which image of the grid the arrival fan walks.  The class walk spends ~1.3x the instructions per step and touches 4-8x fewer
 // cache lines (L2 -> L1 fill 4.4 GB -> 0.5 GB per C3 launch).  Measured (profiles/r03/ray_class_walk.json): on 3-D grids it wins
-// at every ray length (C3: 0.202 against 0.229 ms at 40 cells, 0.66 against 1.12 ms at 160); on a 2-D costmap a short fan lives
+// at every ray length (C3: 0.190 against 0.229 ms at 40 cells, 0.63 against 1.12 ms at 160); on a 2-D costmap a short fan lives
 // in L1 either way and the byte walk's cheaper set-up wins (REF2D: 0.059 against 0.073 ms) until the rays get long.
 // "ray.layout" forces one.
 #ifndef FS_CLASS_WALK_FROM
@@ -1150,6 +1158,7 @@ int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st)
     FS_HIP(c, hipMemcpyAsync(c->d_spheres.p, sph.data(), sizeof(float) * sph.size(), hipMemcpyHostToDevice, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));
     c->m = m; c->n_chunks = n_chunks;
+    reset_voxel_ratio(c);
     // HBM hash tables for tier 3: one per pool workgroup, 2x the landmark count
     int gb = 12;
     while ((1ll << gb) < 2ll * std::max(m, 1)) ++gb;
@@ -1278,6 +1287,7 @@ int fs_set_fim_params(fs_ctx *c, const fs_fim_params *p)
 {
     if (!c || !p) return FS_E_INVALID;
     if (!(p->max_dist > 0.0) || !(p->max_angle > 0.0)) return fail(c, FS_E_INVALID, "max_dist and max_angle must be positive");
+    if (p->max_dist != c->fp.max_dist || p->max_angle != c->fp.max_angle) reset_voxel_ratio(c);
     c->fp = *p;
     return FS_OK;
 }

@@ -446,6 +446,21 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (lane == 0) sh_wave_tested[buf][wave] = tested;         // chunks this wave will scan
     };
 
+    // Pass prediction: distinct voxels <= skip32/32 of the landmarks scanned.  FsFimArgs::skip32 (13/32: p99 0.40 on C3) is the
+    // cap for a cloud nothing is known about; once calls on this cloud have been finished, the largest ratio any candidate
+    // showed (counters[12], in 1/256, kept by the finish kernel; reset with the cloud, the table and the visibility volume)
+    // times 5/4 plus 1/32 takes over when it is smaller (only candidates with >= 16 k landmarks scanned count) — a dense slab seen from inside (REF2D) holds many landmarks per voxel
+    // and was being scored in two passes for nothing.  A candidate that outgrows the prediction overflows its table, goes to
+    // the HBM tier (correct, slower) and raises the ratio for the next call.
+    int skip32_eff = a.skip32;
+    {
+        const uint32_t seen = (uint32_t)a.counters[12];
+        if (seen != 0u) {
+            const int s = (int)((seen * 5u + 31u) / 32u) + 1;
+            skip32_eff = s < skip32_eff ? (s > 2 ? s : 2) : skip32_eff;
+        }
+        skip32_eff = __builtin_amdgcn_readfirstlane(skip32_eff);
+    }
     // ---- prologue: first candidate, factor table
     // Work items are fetched two candidates ahead, by thread 0, behind an iteration's scoring loop (see there).
     if (tid == 0) {
@@ -514,7 +529,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (!GLOBAL_TABLE) {
             // = landmarks scanned * skip32 / 32, in 32 bits (beyond 2^20 accepted chunks the answer is the HBM tier anyway)
             const uint32_t scanned2 = (uint32_t)(wg_tested < (1 << 20) ? wg_tested : (1 << 20)) * 2u;
-            const uint32_t predicted = scanned2 * (uint32_t)a.skip32;
+            const uint32_t predicted = scanned2 * (uint32_t)skip32_eff;
             const int k = (predicted > capacity ? 1 : 0) + (predicted > 2u * capacity ? 1 : 0) + (predicted > 4u * capacity ? 1 : 0) +
                           (predicted > 8u * capacity ? 1 : 0);
             n_parts = 1 << k;                                                         // 1, 2, 4, 8 passes
@@ -738,7 +753,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + qi] = x;
         }
         if (tid == 0) {
-            a.overflow[c] = failed ? fail_code : 0u;                  // the HBM tier re-scores flagged candidates
+            // tier that must re-score the candidate (0: done) | chunks scanned per pass << 4 (the finish kernel's voxel ratio)
+            a.overflow[c] = (failed ? fail_code : 0u) | ((uint32_t)(wg_tested < (1 << 27) ? wg_tested : (1 << 27)) << 4);
             if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);   // landmarks tested (M_tested), summed by the finish kernel
             // what this candidate cost, filed under its block of the map for the order of the next call (fs_sort.hip)
             // (the key was requested with the pose record: a load here would hold thread 0 — and with it the workgroup's next
@@ -809,6 +825,20 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
         if (c < a.n) a.tested[c] = 0u;
         for (int d = 32; d >= 1; d >>= 1) tsum += __shfl_xor(tsum, d);
         if ((threadIdx.x & 63) == 0 && tsum) { atomicAdd(&a.counters[0], tsum); atomicAdd(&a.counters[10], tsum); }
+    }
+    {   // distinct voxels per landmark scanned, in 1/256: the largest any finished candidate showed (fim_worker's pass prediction)
+        uint32_t r = 0u;
+        if (c < a.n) {
+            const uint32_t ov = a.overflow[c], scanned = (ov >> 4) * 64u;
+            // (only candidates big enough to come near the decision count: a pose at the cloud's edge with one chunk of 64 landmarks
+            // in 64 voxels says nothing about the crowded ones)
+            if ((ov & 15u) == 0u && scanned >= 16384u) {
+                const uint32_t nv = (uint32_t)(a.sums[(size_t)c * FS_NACC + 17] + 0.5);
+                r = (uint32_t)(((unsigned long long)nv * 256ull + scanned - 1u) / scanned);
+            }
+        }
+        for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(r, d); r = o > r ? o : r; }
+        if ((threadIdx.x & 63) == 0 && r > (uint32_t)a.counters[12]) atomicMax(&a.counters[12], (unsigned long long)r);
     }
     if (c == 0) {                                            // per-call tier counters -> running totals
         a.counters[4] += a.counters[1];
