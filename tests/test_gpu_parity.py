@@ -157,6 +157,34 @@ def test_fim_voxel_count_saturates(fs, oracle, scorer, ref_table):
     _check_fim(got, want, lm.shape[0])
 
 
+def test_fim_learnt_pass_prediction_is_only_a_prediction(fs, oracle, scorer, ref_table):
+    """The worker predicts a pose's distinct voxels from the largest voxels-per-landmark ratio finished calls have shown on this
+    cloud (fs_fim.hip, counters[12]).  Train it on poses inside a dense clump (0.02 voxels per landmark), then look at a sparse
+    region where nearly every landmark has a voxel of its own: the single pass it predicts overflows, the HBM tier takes the
+    pose — same records as the oracle's — and the ratio it showed is what the next call predicts with."""
+    rng = np.random.default_rng(23)
+    dense = (np.array([4.0, 0.0, 0.0]) + rng.uniform(-1.5, 1.5, size=(60000, 3))).astype(np.float32)
+    sparse = rng.normal(size=(60000, 3))
+    sparse = sparse / np.linalg.norm(sparse, axis=1, keepdims=True) * (13.5 * rng.random(60000) ** (1 / 3))[:, None]
+    sparse[:, 0] = np.abs(sparse[:, 0]) + 200.0                      # a half ball in front of (200, 0, 0)
+    lm = np.concatenate([dense, sparse.astype(np.float32)])
+    near = np.zeros((8, 7)); near[:, 6] = 1.0; near[:, 1] = np.linspace(-0.3, 0.3, 8)
+    far = np.zeros((2, 7)); far[:, 6] = 1.0; far[:, 0] = 200.0; far[1, 2] = 0.2
+    scorer.upload_landmarks(lm)
+    scorer.set_fim_params(14.0, 1.5)
+    hbm0 = scorer.get_counter(5)
+    got = scorer.score_fim(near)
+    _check_fim(got, oracle.pose_information(ref_table, lm, near, 14.0, 1.5, n_threads=8), lm.shape[0])
+    assert got["n_voxels"].max() * 20 < got["n_visible"].max()       # the clump is dense
+    assert scorer.get_counter(5) == hbm0                              # ... and fitted its tables
+    mixed = np.concatenate([near[:4], far])
+    want = oracle.pose_information(ref_table, lm, mixed, 14.0, 1.5, n_threads=8)
+    assert want["n_voxels"][4:].min() > 16384                         # more voxels than an LDS table has slots
+    for _ in range(2):                                                # the second time with the ratio the first one raised
+        _check_fim(scorer.score_fim(mixed), want, lm.shape[0])
+    assert scorer.get_counter(5) > hbm0
+
+
 def _check_fim(got, want, n_lm):
     np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
     np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
