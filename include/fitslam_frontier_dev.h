@@ -30,14 +30,16 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * first (the persistent FIM grid drains better; identical results); "sort.reverse" (default 0): reversed block order, a
  * knob for measuring how much the order matters.
  * "ray.layout" (default 0): which image of the grid the arrival fan walks — 0 picks by ray length (row-major byte image below
- * 96 cells, the 2-bit class image in 16 x 16 x 2-cell tiles from there on: the measured winners), 1 / 2 force the byte / class
+ * 96 cells on 2-D maps, the 2-bit class image in 8 x 8 x 8-cell bricks on 3-D grids and from there on: the measured winners), 1 / 2 force the byte / class
  * walk (identical results in every case; DESIGN.md 4.1 holds the measured table).
  * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
- * landmarks scanned, in 32nds, that decides the number of scoring passes: DESIGN.md 4.2). */
+ * landmarks scanned, in 32nds, that decides the number of scoring passes — the cap under which the worker uses what
+ * finished calls on the cloud have shown: DESIGN.md 4.2). */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
 /* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
  * 4 = candidates scored in several voxel-partitioned passes, 5 = candidates re-scored with the table in HBM,
- * 6 = unresolved (always 0). */
+ * 6 = unresolved (always 0), 12 = the largest voxels-per-landmark ratio (in 1/256) a big candidate of the finished calls
+ * showed (the pass prediction's input; reset with the cloud, the table and the visibility volume). */
 int  fs_get_counter(fs_ctx *ctx, int which, int64_t *value, int reset);
 
 /* ---------------------------------------------------------------- self test */
