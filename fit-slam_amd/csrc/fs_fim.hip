@@ -405,9 +405,11 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // condition is "a difference is >= 0" (exact in floating point), AND is a minimum, OR a maximum — straight-line code, no
         // exec-mask nesting (three levels of it and their scalar bookkeeping in the branchy version).  A lane without a chunk
         // holds a sphere of radius -1e30: its reach is negative.
-        const unsigned long long live = dead ? 0ull : ~0ull;
-        auto cull_one = [&](int j, const float4 s) -> bool {
-            if (!a.cull) return j < a.n_chunks;                       // brute force (wave-uniform)
+        // (returned as the float whose sign decides, so that the ballot is the mask of ONE compare — a boolean merged from the
+        // two branches is materialised with a select and a second compare, and ANDing a "candidate is alive" mask on top costs
+        // three scalar instructions per pass: a dead candidate writes empty masks instead)
+        auto cull_one = [&](int j, const float4 s) -> float {
+            if (!a.cull) return j < a.n_chunks ? 0.0f : -1.0f;        // brute force (wave-uniform)
             const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;
             const float d2 = dx * dx + dy * dy + dz * dz;
             const float reach = a.max_dist_f + s.w, r2 = s.w * s.w;
@@ -421,8 +423,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 const float lhs = dot - (a.cos_a * h - a.sin_a * s.w - (1.0e-4f * reach + 1.0e-4f));     // |d| <= reach here
                 c = fminf(c, fmaxf(lhs, r2 - d2));
             }
-            return c >= 0.0f;
+            return c;
         };
+        if (dead) {
+            if (lane == 0) {
+                for (int g = 0; g < a.n_groups; ++g) masks[g] = 0ull;
+                sh_wave_tested[buf][wave] = 0;
+            }
+            return;
+        }
         for (int gb = 0; gb < a.n_groups; gb += 4) {
             float4 sp[4];
 #pragma unroll
@@ -437,7 +446,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             for (int u = 0; u < 4; ++u) {
                 if (gb + u < a.n_groups) {
                     const int j = (gb + u) * STRIDE + lane * WAVES + wave;
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(cull_one(j, sp[u])) & live;
+                    float c = cull_one(j, sp[u]);
+                    asm volatile("" : "+v"(c));               // (keeps the compare out here, behind the merge of the two branches)
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(c >= 0.0f);
                     tested += __popcll(mask);
                     if (lane == 0) masks[gb + u] = mask;
                 }
@@ -633,7 +644,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     else if (a.cone_mode == 2) v = v && ((px >= 0.0f) || (px2 <= a.cos2 * n2));
                     m3 = v ? 0.0f : -1.0f;
                 }
-                if (n_parts > 1) m3 = (voxel_part(a, true, px, n_parts) == part) ? m3 : -1.0f;   // wave-uniform branch; every lane evaluates
+                if (__builtin_expect(n_parts > 1, 0)) m3 = (voxel_part(a, true, px, n_parts) == part) ? m3 : -1.0f;   // wave-uniform branch (out of line: a taken branch costs a wave its instruction buffer); every lane evaluates
                 const bool vis = m3 >= 0.0f;
                 // ---- 3. compact
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(vis);
