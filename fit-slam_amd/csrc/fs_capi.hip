@@ -335,7 +335,9 @@ void generate_records(float minX, float maxX, float minY, float maxY, float minZ
 // what it learnt holds for one cloud, one table and one visibility volume.
 static void reset_voxel_ratio(fs_ctx *c)
 {
-    if (c->d_counters.p) (void)hipMemsetAsync(c->d_counters.p + 12, 0, sizeof(unsigned long long), c->stream);
+    if (!c->d_counters.p) return;
+    (void)hipSetDevice(c->device);                         // (callers on the table path have not bound the device yet)
+    (void)hipMemsetAsync(c->d_counters.p + 12, 0, sizeof(unsigned long long), c->stream);
 }
 
 // Dense re-indexing of the record list by the integer voxel lattice (what loadLookupTable's
