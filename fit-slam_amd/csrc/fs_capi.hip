@@ -501,6 +501,13 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     a.maxd2 = (float)(c->fp.max_dist * c->fp.max_dist);
     a.max_dist_f = (float)c->fp.max_dist * 1.0001f + 1.0e-3f;      // culling reach, rounded outwards
     a.far_lattice = !((double)a.max_dist_f * a.inv_step < 1000.0) ? 1 : 0;   // (NaN / inf / huge ranges: exact path for every landmark)
+    {   // fl32(p * fl32(1/step)) is within |r| * 2^-23 of the double product the reference rounds (one rounding of the factor, one of
+        // the product); twice that at the largest |r| a scored landmark can have, plus an absolute cushion, is the band around a
+        // half-integer inside which the kernel re-evaluates in fp64 (0.4995 covered |r| < 2^10 wholesale: 40 times the lanes at 14 m)
+        const double r_max = std::max(1.0, (double)a.max_dist_f * a.inv_step);
+        const double band = 2.0 * r_max * 1.1920929e-7 + 1.0e-6;
+        a.key_thr = a.far_lattice ? 0.0f : (float)(0.5 - band);
+    }
     if (c->fp.max_angle >= M_PI) {
         a.cone_mode = 0; a.cos2 = 0.0f; a.cos_a = -1.0f; a.sin_a = 0.0f;
     } else {

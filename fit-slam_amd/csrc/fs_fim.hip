@@ -104,7 +104,8 @@ __device__ __forceinline__ uint32_t hash_key(uint32_t key, int bits)
 // getVoxelCoordinate (FisherInfoManager.hpp:119-121), exactly.  The fp32 product is within |r| * 1.3e-7 of the fp64
 // one (|r| < 2^10: every scored landmark lies within max_dist of the camera, and the host sets FsFimArgs::far_lattice when
 // max_dist / step could reach 2^10 — then every lane takes the fp64 path), so away from a .5 boundary the fp32 nearest integer
-// equals the fp64 half-away-from-zero result; lanes next to a boundary (0.1 %) re-evaluate the fp64 expression.
+// equals the fp64 half-away-from-zero result; lanes within FsFimArgs::key_thr' = 0.5 - key_thr of a boundary — twice the
+// error bound at the largest |r| the visibility range allows, 1.2e-5 at 14 m — re-evaluate the fp64 expression.
 // in_table: the voxel lies inside the table box.
 __device__ __forceinline__ uint32_t voxel_key(const FsFimArgs &a, bool active, float px, float py, float pz, bool &in_table)
 {
@@ -112,7 +113,7 @@ __device__ __forceinline__ uint32_t voxel_key(const FsFimArgs &a, bool active, f
     const float nx = rintf(rx), ny = rintf(ry), nz = rintf(rz);
     int jx = (int)nx, jy = (int)ny, jz = (int)nz;
     const float worst = fmaxf(fmaxf(fabsf(rx - nx), fabsf(ry - ny)), fabsf(rz - nz));
-    if (active && (a.far_lattice || !(worst < 0.4995f))) {
+    if (active && (a.far_lattice || !(worst < a.key_thr))) {
         jx = (int)round((double)px * a.inv_step);
         jy = (int)round((double)py * a.inv_step);
         jz = (int)round((double)pz * a.inv_step);
@@ -135,7 +136,7 @@ __device__ __forceinline__ int voxel_part(const FsFimArgs &a, bool active, float
     const float rx = px * a.inv_step_f;
     const float nx = rintf(rx);
     int jx = (int)nx;
-    if (active && (a.far_lattice || !(fabsf(rx - nx) < 0.4995f))) jx = (int)round((double)px * a.inv_step);
+    if (active && (a.far_lattice || !(fabsf(rx - nx) < a.key_thr))) jx = (int)round((double)px * a.inv_step);
     return (jx + 4096) & (n_parts - 1);
 }
 

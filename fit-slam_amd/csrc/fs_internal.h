@@ -145,6 +145,7 @@ struct FsFimArgs {
     double inv_step;           // 1 / (double)0.3f  (FisherInfoManager.hpp:119)
     float inv_step_f;          // (float)inv_step, fast path of the voxel index
     int32_t far_lattice;       // 1: max_dist / step may reach 2^10 lattice cells — the fp32 fast path of the voxel index is not proven there
+    float key_thr;             // fast path accepted while |r - rint(r)| < key_thr = 0.5 - 2 * (error bound of the fp32 product at the largest |r|)
     const float *factor;       // crowding factor by rank, [FS_FACTOR_N]; rank >= FS_FACTOR_N -> 0
     float fac1, fac2, fac3, fac4;   // factor[1..4]
     int32_t table_full;        // 1: only finite values inside the table box (true for every generated table)

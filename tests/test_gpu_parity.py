@@ -185,6 +185,35 @@ def test_fim_learnt_pass_prediction_is_only_a_prediction(fs, oracle, scorer, ref
     assert scorer.get_counter(5) > hbm0
 
 
+def test_fim_voxel_rounding_next_to_the_boundary(fs, oracle, scorer, ref_table):
+    """getVoxelCoordinate rounds x / step in double; the kernel rounds an fp32 product and re-evaluates in fp64 only inside a band
+    around the half-integers whose width follows the visibility range (FsFimArgs::key_thr).  Landmarks ON the boundaries and a
+    few ulps either side of them, at every lattice index the range allows: the voxel of every one of them must be the oracle's."""
+    step = np.float64(np.float32(0.3))
+    k = np.arange(0, 46, dtype=np.float64)
+    base = ((k + 0.5) * step).astype(np.float32)                     # x on (or one rounding off) a voxel boundary
+    xs = [base]
+    for ulps in (1, 2, 3, 5, 9, 17, 40, 100, 400):
+        up, dn = base.copy(), base.copy()
+        for _ in range(ulps if ulps < 40 else 0):
+            up, dn = np.nextafter(up, np.float32(np.inf)), np.nextafter(dn, np.float32(-np.inf))
+        if ulps >= 40:
+            up, dn = base * np.float32(1 + ulps * 6e-8), base * np.float32(1 - ulps * 6e-8)
+        xs += [up, dn]
+    x = np.concatenate(xs)
+    rng = np.random.default_rng(3)
+    lm = np.stack([x, rng.uniform(-0.1, 0.1, x.size).astype(np.float32), rng.uniform(-0.1, 0.1, x.size).astype(np.float32)], axis=1)
+    lm = np.concatenate([lm, lm[:, [1, 0, 2]] * np.float32([1, 0.3, 1]) + np.float32([2.0, 0, 0]), lm[:, [1, 2, 0]] * np.float32([1, 1, 0.3]) + np.float32([2.0, 0, 0])])
+    pose = np.array([[0, 0, 0, 0, 0, 0, 1.0]])
+    scorer.upload_landmarks(lm)
+    for max_dist in (14.0, 30.0):
+        scorer.set_fim_params(max_dist, 1.5)
+        got = scorer.score_fim(pose)
+        want = oracle.pose_information(ref_table, lm, pose, max_dist, 1.5, n_threads=1)
+        assert want["n_visible"][0] > 500
+        _check_fim(got, want, lm.shape[0])
+
+
 def _check_fim(got, want, n_lm):
     np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
     np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
