@@ -1,7 +1,10 @@
-"""Development stress run (GPU box): random clouds / poses / visibility volumes / tables through fs_score_fim against the
-oracle — integers exactly, FI to the tolerance of the parity tests.  Not part of the suite (minutes, random by design):
+"""Random clouds / poses / visibility volumes / tables through fs_score_fim against the oracle — integers exactly, FI to the
+tolerance of the parity tests.  test_gpu_fim_random.py runs a fixed-seed slice of it in the suite; by hand (GPU box), for as
+many trials as one likes:
 
-    python tools/fim_stress.py [trials] [seed]
+    python tests/fim_random.py [trials] [seed]
+
+(Lives under tests/ because it uses the oracle: the checker is test infrastructure.)
 """
 import importlib
 import os
