@@ -841,12 +841,13 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
     {   // distinct voxels per landmark scanned, in 1/256: the largest any finished candidate showed (fim_worker's pass prediction)
         uint32_t r = 0u;
         if (c < a.n) {
-            const uint32_t ov = a.overflow[c], scanned = (ov >> 4) * 64u;
+            const uint32_t ov = a.overflow[c];
+            const unsigned long long scanned = (unsigned long long)(ov >> 4) * 64ull;
             // (only candidates big enough to come near the decision count: a pose at the cloud's edge with one chunk of 64 landmarks
             // in 64 voxels says nothing about the crowded ones)
-            if ((ov & 15u) == 0u && scanned >= 16384u) {
+            if ((ov & 15u) == 0u && scanned >= 16384ull) {
                 const uint32_t nv = (uint32_t)(a.sums[(size_t)c * FS_NACC + 17] + 0.5);
-                r = (uint32_t)(((unsigned long long)nv * 256ull + scanned - 1u) / scanned);
+                r = (uint32_t)(((unsigned long long)nv * 256ull + scanned - 1ull) / scanned);
             }
         }
         for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(r, d); r = o > r ? o : r; }

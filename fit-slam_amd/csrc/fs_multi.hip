@@ -63,7 +63,13 @@ int for_all_parallel(fs_multi *m, const char *what, F call)
     } else {
         std::vector<std::thread> workers;
         workers.reserve(n);
-        for (size_t i = 0; i < n; ++i) workers.emplace_back([&, i] { rc[i] = call(m->ctx[i]); });
+        for (size_t i = 0; i < n; ++i) {
+            try {
+                workers.emplace_back([&, i] { rc[i] = call(m->ctx[i]); });
+            } catch (...) {                                   // no thread to be had: this member's copy runs here, after the others
+                rc[i] = call(m->ctx[i]);
+            }
+        }
         for (std::thread &t : workers) t.join();
     }
     for (size_t i = 0; i < n; ++i)
