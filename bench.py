@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--workload", default="C3", help="C3 (headline) | C5 | REF2D (the reference's own 2-D operating point: 63 rays, L = 40) | C2 | C1")
     ap.add_argument("--depth-cells", type=int, default=0, help="ray length L in cells (0: the config's 40 = 2 m; BASELINE.md's secondary throughput run uses 160)")
+    ap.add_argument("--fim-angle", type=float, default=1.0, help="visibility cone half-angle in rad for the timed steps (1.0: the build's definition, SURVEY.md App. A.3; 4.0 = the reference's own request, FisherInfoManager.cpp:63-64: cone off).  The N = 1 line always carries the other one under other_operating_points.reference_request_visibility")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time (three runs, median); 0 disables")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the measured configuration) | gloo (rehearsal of the N > 1 path on one GPU: ranks share the device, records are gathered through host memory)")
@@ -140,7 +141,17 @@ def counter_profile(workload: str, depth_cells: int):
     return j
 
 
-def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx, fim_angle=1.0):
     """Time the oracle (kind 'port') on a bounded sample of the same workload, single thread, three runs (median), and
     gate the GPU records of that sample against it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -156,7 +167,7 @@ def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx):
         arr = O.arrival_information(G, P, w.goals[lo:hi], w.frontier_size[lo:hi], w.blacklisted[lo:hi],
                                     min_gt=mx["min_gt"], faithful=faithful, n_threads=threads, want_ray_counts=False)
         poses = O.poses_from_yaw(w.goals[lo:hi], arr["yaw"])
-        fim = O.pose_information(table, w.landmarks, poses, 14.0, 1.0, n_threads=threads, want_f64=True)
+        fim = O.pose_information(table, w.landmarks, poses, 14.0, fim_angle, n_threads=threads, want_f64=True)
         return time.perf_counter() - t0, arr, fim
 
     probe = min(32, n_total)
@@ -169,6 +180,7 @@ def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx):
         times.append(dt)
     med = float(np.median(times))
     out = {"value": n_s / med, "unit": "candidate-goals/s", "cores": 1, "kind": "port",
+           "cpu_model": cpu_model(), "host_cores_visible": os.cpu_count(),
            "sample": f"first {n_s} of {n_total} candidates of the same workload, oracle/ C restatement "
                      f"(reference-faithful control flow), single thread, median of 3 runs of {med:.1f} s",
            "runs_s": times, "min_run_value": n_s / max(times), "max_run_value": n_s / min(times)}
@@ -190,8 +202,18 @@ def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx):
         sc = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
         e_info = float(np.max(np.abs(r["info_ref"][ok] - fim["info_f64"][ok]) / sc)) if ok.any() else 0.0
         e_tr = float(np.max(np.abs(r["trace"][ok] - fim["trace"][ok]) / np.maximum(fim["trace"][ok], 1e-6))) if ok.any() else 0.0
+        # D-optimality: no reference counterpart (the reference keeps the trace only) — against the float64 oracle, relative to
+        # max(1, |log det|), over the candidates where both are finite; the share within north_star's 1e-4 is reported
+        fin = ok & np.isfinite(fim["logdet"]) & np.isfinite(r["logdet"])
+        e_ld = np.abs(r["logdet"][fin] - fim["logdet"][fin]) / np.maximum(1.0, np.abs(fim["logdet"][fin]))
+        same_sing = bool(np.array_equal(np.isfinite(r["logdet"][ok]), np.isfinite(fim["logdet"][ok])))
         parity = {"n": int(n_s), "integers_bit_exact": bool(ints), "info_max_rel_err": e_info,
-                  "trace_max_rel_err": e_tr, "ok": bool(ints and e_info <= 1e-4 and e_tr <= 1e-4)}
+                  "trace_max_rel_err": e_tr,
+                  "logdet_max_rel_err": float(e_ld.max()) if e_ld.size else 0.0,
+                  "logdet_share_within_1e-4": float(np.mean(e_ld <= 1e-4)) if e_ld.size else 1.0,
+                  "logdet_finite_candidates": int(fin.sum()), "logdet_singularity_agrees": same_sing,
+                  "visibility": f"14 m, {fim_angle} rad",
+                  "ok": bool(ints and e_info <= 1e-4 and e_tr <= 1e-4 and (e_ld.size == 0 or e_ld.max() <= 1e-4))}
     return out, parity
 
 
@@ -216,14 +238,14 @@ def run_latency(args) -> int:
     O.build()
     table = O.Table.generate()
     out = {"metric": "latency of one scoring call at the reference's operating point (host buffers in, results out, synchronised)",
-           "unit": "us", "calls_per_figure": args.latency_calls, "workloads": {}}
+           "unit": "us", "visibility": f"14 m, {args.fim_angle} rad" + (" (cone off: the reference's request)" if args.fim_angle >= np.pi else ""), "calls_per_figure": args.latency_calls, "workloads": {}}
     for wl in ("REF2D", "C1"):
         w = fs.synth.make_workload(wl, n_cand=2000)
         kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
                   robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
         sc = fs.FrontierScorer(device=0)
         sc.set_ray_params(**kw); sc.upload_grid(w.cells, w.origin, w.resolution); sc.upload_landmarks(w.landmarks)
-        sc.lookup_generate(); sc.set_fim_params(14.0, 1.0)
+        sc.lookup_generate(); sc.set_fim_params(14.0, args.fim_angle)
         mx = sc.max_arrival()
         G = O.Grid(w.cells, origin=w.origin, resolution=w.resolution)
         P = O.RayParams(**kw)
@@ -242,7 +264,7 @@ def run_latency(args) -> int:
                 rec_all = rec
             t0 = time.perf_counter()
             arr = O.arrival_information(G, P, g, f, b, min_gt=mx["min_gt"], faithful=True, n_threads=1, want_ray_counts=False)
-            fim = O.pose_information(table, w.landmarks, O.poses_from_yaw(g, arr["yaw"]), 14.0, 1.0, n_threads=1, want_f64=True)
+            fim = O.pose_information(table, w.landmarks, O.poses_from_yaw(g, arr["yaw"]), 14.0, args.fim_angle, n_threads=1, want_f64=True)
             cpu_us = (time.perf_counter() - t0) * 1e6
             ok = bool(np.array_equal(rec["arrival"], arr["arrival"]) and np.array_equal(rec["n_visible"][arr["status"] == 0], fim["n_visible"][arr["status"] == 0]))
             res["score_candidates"][str(n)] = dict(_percentiles(ts), cpu_oracle_1thread_us=cpu_us, parity_integers=ok)
@@ -256,9 +278,19 @@ def run_latency(args) -> int:
             r1 = sc.score_fim(pose, want_fim=False)
             ts.append((time.perf_counter() - t0) * 1e6)
         t0 = time.perf_counter()
-        f1 = O.pose_information(table, w.landmarks, pose, 14.0, 1.0, n_threads=1, want_f64=False)
+        f1 = O.pose_information(table, w.landmarks, pose, 14.0, args.fim_angle, n_threads=1, want_f64=False)
         res["score_fim_1_pose"] = dict(_percentiles(ts), cpu_oracle_1thread_us=(time.perf_counter() - t0) * 1e6,
                                        parity_integers=bool(r1["n_visible"][0] == f1["n_visible"][0]))
+        # the same pose asked for info_ref alone — the call FisherInformationManager::isPoseSafe makes (INFO_ONLY worker)
+        for _ in range(20):
+            sc.score_fim(pose, info_only=True)
+        ts = []
+        for _ in range(args.latency_calls):
+            t0 = time.perf_counter()
+            r2 = sc.score_fim(pose, info_only=True)
+            ts.append((time.perf_counter() - t0) * 1e6)
+        res["score_fim_1_pose_info_only"] = dict(_percentiles(ts), parity_integers=bool(r2["n_voxels"][0] == f1["n_voxels"][0]),
+                                                 info_rel_err=float(abs(r2["info_ref"][0] - f1["info_ref"][0]) / max(abs(float(f1["info_ref"][0])), 1e-6)))
         if wl == "REF2D":
             # frontier detection + clustering on the 512^2 costmap, robot on a free cell (fs_frontier_clusters), and the whole
             # FrontierSearch::searchFrom of the oracle (the reference's two nested breadth-first searches) beside it
@@ -281,6 +313,100 @@ def run_latency(args) -> int:
         out["workloads"][wl] = res
     print(json.dumps(out), flush=True)
     return 0
+
+
+def other_visibility(args, sc, w, n_local, d_goal, d_fsize, d_black, d_rec, dev, mx, arrival_kw):
+    """The same workload at the OTHER visibility volume: the timed steps use --fim-angle (default: the build's 1.0 rad cone),
+    this entry the reference's own request — 14 m, cone off (max_angle 4.0, FisherInfoManager.cpp:63-64; the ROS adapter's
+    default) — or the other way round.  Two figures: the fused step (full records; YAW_ONLY worker) and ONE fs_score_fim call
+    over the step's poses that asks for info_ref alone (the INFO_ONLY worker: what isPoseSafe reads), both with their kernel
+    time, landmarks tested per candidate, pass and HBM-tier counts, and gated against the oracle on a sample."""
+    import torch
+    shard = importlib.import_module("fit-slam_amd.shard")
+    angle = 4.0 if args.fim_angle < np.pi else 1.0
+    sc.set_fim_params(14.0, angle)
+    out = {"max_dist": 14.0, "max_angle": angle,
+           "note": "same workload and build, other visibility volume; never `value`"}
+    try:
+        def fused():
+            sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_rec.data_ptr())
+        for _ in range(3):
+            fused()
+        torch.cuda.synchronize(dev)
+        for k in (0, 1, 2, 4):
+            sc.kernel_time(k)
+        sc.get_counter(0, reset=True)
+        mp0, t30 = sc.get_counter(4), sc.get_counter(5)
+        reps = max(5, args.steps)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fused()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / reps
+        out["fused_step"] = {"ms_per_step": dt * 1e3, "candidate_goals_per_s": n_local / dt,
+                             "m_tested_per_candidate": sc.get_counter(0, reset=True) / (reps * n_local),
+                             "multi_pass_candidates_per_step": (sc.get_counter(4) - mp0) / reps,
+                             "hbm_table_candidates_per_step": (sc.get_counter(5) - t30) / reps}
+        sc.enable_kernel_timing(True)
+        for _ in range(reps):
+            fused()
+        torch.cuda.synchronize(dev)
+        ray_ms, ray_n = sc.kernel_time(0)
+        fim_ms, fim_n = sc.kernel_time(1)
+        ovf_ms, _ = sc.kernel_time(2)
+        sc.kernel_time(4)
+        out["fused_step"].update({"fs_raymarch_kernel_ms": ray_ms / max(ray_n, 1), "fs_fim_kernel_ms": fim_ms / max(fim_n, 1),
+                                  "fs_fim_overflow_kernel_ms": ovf_ms / max(fim_n, 1), "fim_worker": "YAW_ONLY, cone " + ("off" if angle >= np.pi else "1.0 rad")})
+        sc.enable_kernel_timing(False)
+        rec = shard.records_to_numpy(d_rec[:n_local])
+        # the step's poses through fs_score_fim, info_ref alone (host poses in, two columns out: PCIe included in ms_per_call)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O   # pose construction for the call + the checker of the sample below
+        # (the pose of a candidate: goal + the yaw of its best window in DOUBLE, argmax * delta_theta + fov / 2 as
+        # CostCalculator.cpp:119 — the record's float32 yaw would turn the camera by 1e-7 rad and move landmarks across voxel faces)
+        poses = O.poses_from_yaw(w.goals[:n_local], rec["argmax"].astype(np.float64) * w.delta_theta + w.camera_fov / 2)
+        for _ in range(2):
+            r_info = sc.score_fim(poses, info_only=True)
+        sc.get_counter(0, reset=True)
+        mp0, t30 = sc.get_counter(4), sc.get_counter(5)
+        sc.enable_kernel_timing(True)
+        sc.kernel_time(1); sc.kernel_time(2)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r_info = sc.score_fim(poses, info_only=True)
+        dt = (time.perf_counter() - t0) / reps
+        fim_ms, fim_n = sc.kernel_time(1)
+        ovf_ms, _ = sc.kernel_time(2)
+        sc.enable_kernel_timing(False)
+        out["info_only_call"] = {"ms_per_call": dt * 1e3, "poses_per_s": n_local / dt, "fs_fim_kernel_ms": fim_ms / max(fim_n, 1),
+                                 "fs_fim_overflow_kernel_ms": ovf_ms / max(fim_n, 1),
+                                 "m_tested_per_pose": sc.get_counter(0, reset=True) / (reps * n_local),
+                                 "multi_pass_poses_per_call": (sc.get_counter(4) - mp0) / reps,
+                                 "hbm_table_poses_per_call": (sc.get_counter(5) - t30) / reps,
+                                 "learnt_voxels_per_landmark_scanned": sc.get_counter(12) / 256.0,
+                                 "fim_worker": "INFO_ONLY (no 6x6 sums, exact table-box cull), cone " + ("off" if angle >= np.pi else "1.0 rad"),
+                                 "note": "fs_score_fim(n = all poses of the step) with NULL for every column but info_ref / n_voxels — what FisherInformationManager::isPoseSafe reads; host poses in, PCIe both ways included in ms_per_call"}
+        if args.cpu_seconds > 0:
+            O.build()
+            n_s = min(n_local, 192)
+            ok = ((rec["flags"][:n_s] >> 8) & 0xFF) == 0
+            fim = O.pose_information(O.Table.generate(), w.landmarks, poses[:n_s], 14.0, angle, n_threads=min(16, os.cpu_count() or 1), want_f64=True)
+            sc_ = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
+            nv = np.minimum(fim["n_voxels"], 65535)
+            # (a pose whose candidate was off the map / blacklisted is still a pose for fs_score_fim: compared on all of them)
+            sc_all = np.maximum(np.abs(fim["info_f64"]), 1e-6)
+            out["parity"] = {"n": int(n_s),
+                             "fused_n_visible_bit_exact": bool(np.array_equal(rec["n_visible"][:n_s][ok], fim["n_visible"][ok])),
+                             "fused_n_voxels_bit_exact": bool(np.array_equal(((rec["flags"][:n_s] >> 16) & 0xFFFF)[ok], nv[ok])),
+                             "fused_info_max_rel_err": float(np.max(np.abs(rec["info_ref"][:n_s][ok] - fim["info_f64"][ok]) / sc_)) if ok.any() else 0.0,
+                             "info_only_n_voxels_bit_exact": bool(np.array_equal(r_info["n_voxels"][:n_s], fim["n_voxels"])),
+                             "info_only_info_max_rel_err": float(np.max(np.abs(r_info["info_ref"][:n_s] - fim["info_f64"]) / sc_all))}
+            p = out["parity"]
+            p["ok"] = bool(p["fused_n_visible_bit_exact"] and p["fused_n_voxels_bit_exact"] and p["info_only_n_voxels_bit_exact"]
+                           and p["fused_info_max_rel_err"] <= 1e-4 and p["info_only_info_max_rel_err"] <= 1e-4)
+    finally:
+        sc.set_fim_params(14.0, args.fim_angle)
+    return out
 
 
 def dry_run(args, rank, world) -> int:
@@ -389,7 +515,7 @@ def run_rank(args) -> int:
             c.upload_grid(w.cells, w.origin, w.resolution)
         c.upload_landmarks(w.landmarks)
         c.lookup_generate()
-        c.set_fim_params(14.0, 1.0)
+        c.set_fim_params(14.0, args.fim_angle)
     del bricks
     mx = sc.max_arrival()
 
@@ -528,6 +654,10 @@ def run_rank(args) -> int:
         extra["rank_candidates_call"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3,
                                          "note": "fs_rank_candidates over one step's records: utilities, weighted cost and order, host columns both ways"}
 
+    if world == 1 and not args.no_parity:
+        extra["reference_request_visibility" if args.fim_angle < np.pi else "build_cone_visibility"] = other_visibility(
+            args, sc, w, n_local, d_goal, d_fsize, d_black, torch.zeros_like(d_recs[0]), dev, mx, arrival_kw)
+
     if world > 1:
         tmax = torch.tensor(block_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -553,7 +683,7 @@ def run_rank(args) -> int:
         gpu_rec = shard.records_to_numpy(full) if not args.no_parity else None
         cpu, parity = (None, None)
         if world == 1 and args.cpu_seconds > 0:
-            cpu, parity = cpu_baseline(w, arrival_kw, n_total, args.cpu_seconds, gpu_rec, mx)
+            cpu, parity = cpu_baseline(w, arrival_kw, n_total, args.cpu_seconds, gpu_rec, mx, args.fim_angle)
         per_rank = n_total // world if args.scaling == "strong" else cfg["n_cand"]
         roofline = {
             # the roofline the fraction below is priced against: the HBM one the metric asks for (algorithmic bytes / time / 8 TB/s).
@@ -585,7 +715,8 @@ def run_rank(args) -> int:
             "vs_baseline": None, "dtype": "u8 grid walk (int32/fp64 set-up) + f32 FIM", "data": "synthetic",
             "config": {"workload": f"{wl_name}: {cfg['n']}^{3 if cfg['nz'] > 1 else 2} uint8 grid ({grid_note}), {per_rank} candidates/GPU "
                                    f"({n_total} total), {m} landmarks, {R * E} rays/candidate ({R} yaw x {E} elevation), "
-                                   f"L={L} cells, chunk-culled visibility (M_tested measured), reference 71x100x100 lookup table",
+                                   f"L={L} cells, visibility 14 m / {args.fim_angle} rad{' (cone off: the reference request)' if args.fim_angle >= np.pi else ''}, "
+                                   f"chunk-culled (M_tested measured), reference 71x100x100 lookup table",
                        "candidates_per_gpu": per_rank, "total_candidates": n_total,
                        "sharding": f"contiguous blocks over {world} GPU(s), one all-gather of 32-B records ({args.backend})",
                        "pipeline": f"{n_pipe} scorer context(s)/HIP stream(s) per GPU; batch k runs whole on context k mod {n_pipe}"},

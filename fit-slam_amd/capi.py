@@ -322,10 +322,16 @@ class FrontierScorer:
         p = FimParamsC(max_dist, max_angle)
         self._check(self._L.fs_set_fim_params(self._h, C.byref(p)))
 
-    def score_fim(self, pose7, want_fim=True):
+    def score_fim(self, pose7, want_fim=True, info_only=False):
+        """info_only: what isPoseSafe itself needs — info_ref (and n_voxels); every other column is passed as NULL, which
+        selects the worker without the 6x6 sums and with the exact table-box cull."""
         ps = np.ascontiguousarray(pose7, dtype=np.float64).reshape(-1, 7)
         n = ps.shape[0]
         info = np.zeros(n, dtype=np.float32)
+        if info_only:
+            nvox = np.zeros(n, dtype=np.int32)
+            self._check(self._L.fs_score_fim(self._h, n, _p(ps), _p(info), None, None, None, None, _p(nvox)))
+            return dict(info_ref=info, n_voxels=nvox)
         fim21 = np.zeros((n, 21), dtype=np.float32) if want_fim else None
         trace = np.zeros(n, dtype=np.float32); logdet = np.zeros(n, dtype=np.float32)
         nvis = np.zeros(n, dtype=np.int32); nvox = np.zeros(n, dtype=np.int32)

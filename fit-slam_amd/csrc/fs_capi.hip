@@ -102,6 +102,8 @@ struct fs_ctx {
     int32_t m = 0, n_chunks = 0;
     DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
     bool opt_cull = true;
+    bool opt_special = true;       // "fim.specialise": the INFO_ONLY / YAW_ONLY workers where they apply (0: always the general worker)
+    bool yaw_exact = false;        // every rotation of d_yawR is about Z with exact zeros / one (what YAW_ONLY relies on)
     int opt_bits1 = 14;            // development knobs (fs_set_option "fim.bits1", "fim.skip32")
     int opt_skip32 = 13;
     DevBuf<unsigned long long> d_counters;
@@ -523,6 +525,18 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     // scored in passes; the HBM tier behind it takes what still overflows
     int bits = 10;
     while (bits < c->opt_bits1 && (1 << bits) < 2 * c->m) ++bits;
+    // the table's box in the camera frame: lattice index j holds |p / step - j| <= 0.5, so a landmark outside
+    // [(j0 - 0.5) step, (j0 + t - 0.5) step] on any axis misses the table whatever the others are; 1 mm outwards covers the
+    // rounding of the kernel's fp32 products (|p| <= max_dist).  Used by the INFO_ONLY worker only.
+    {
+        const double step = (double)kStepMax;
+        const int32_t j0[3] = {c->jx0, c->jy0, c->jz0}, tn[3] = {c->tx, c->ty, c->tz};
+        for (int k = 0; k < 3; ++k) {
+            a.box_lo[k] = std::nextafter((float)(((double)j0[k] - 0.5) * step - 1.0e-3), -INFINITY);
+            a.box_hi[k] = std::nextafter((float)(((double)(j0[k] + tn[k]) - 0.5) * step + 1.0e-3), INFINITY);
+        }
+    }
+    a.info_only = 0; a.yaw_only = 0;
     a.hash_bits = bits;
     a.skip32 = c->opt_skip32;
     a.gtable = c->d_gtable.p;
@@ -708,6 +722,11 @@ int fs_set_ray_params(fs_ctx *c, const fs_ray_params *p)
         pose_to_rt(pose7, Rt);
         std::copy(Rt, Rt + 9, &yawR[(size_t)i * 9]);
     }
+    bool yaw_exact = true;
+    for (int i = 0; i < n_win; ++i) {
+        const float *R = &yawR[(size_t)i * 9];
+        yaw_exact = yaw_exact && R[2] == 0.0f && R[5] == 0.0f && R[6] == 0.0f && R[7] == 0.0f && R[8] == 1.0f;
+    }
     FS_HIP(c, c->d_dir.ensure(dir.size()));
     FS_HIP(c, c->d_yawR.ensure(yawR.size()));
     FS_HIP(c, hipMemcpyAsync(c->d_dir.p, dir.data(), dir.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -715,6 +734,7 @@ int fs_set_ray_params(fs_ctx *c, const fs_ray_params *p)
     FS_HIP(c, hipStreamSynchronize(c->stream));
     c->rp = *p;
     c->n_yaw = n_yaw; c->n_elev = p->n_elev; c->window = k;
+    c->yaw_exact = yaw_exact;
     c->have_ray = true;
     c->max_gt = 0.0; c->min_gt = 0.0;
     return FS_OK;
@@ -1193,6 +1213,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
 {
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "fim.specialise") == 0) { c->opt_special = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
@@ -1369,6 +1390,13 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
         if (!(std::fabs(nq - 1.0) <= 1.0e-4)) a.cull = 0;
     }
     a.fim21 = fim21 ? c->d_fim21.p : nullptr;
+    // isPoseSafe reads the scalar alone (FIP/src/fisher_information/FisherInfoManager.cpp:83-100): a call that asks for nothing
+    // but info_ref (and, at no cost, n_voxels) takes the worker without the 6x6 sums and with the exact table-box cull
+    a.info_only = (c->opt_special && !fim21 && !trace && !logdet && !n_visible) ? 1 : 0;
+    // (the box cull leaves only chunks that can hold voxels of the table, so a pose shows more distinct voxels per landmark
+    // scanned than the 13/32 the general worker caps its pass prediction at — C3, cone off: up to 0.5; an extra pass costs a
+    // re-test of the landmarks, an overflow the HBM tier)
+    if (a.info_only && a.skip32 < 20) a.skip32 = 20;
     rc = run_fim(c, a);
     if (rc) return rc;
     struct Col { void *host; const void *dev; size_t bytes; };
@@ -1557,6 +1585,7 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     fa.status = c->d_status.p;
     if (ra.perm && c->opt_costmap) { fa.costmap = c->sort_costmap; fa.cand_key = c->sort_keys; }   // heavy blocks first next time
     fa.fim21 = nullptr;
+    fa.yaw_only = (c->opt_special && c->yaw_exact) ? 1 : 0;   // the ray-march kernel copies the pose's rotation out of d_yawR
     bind_fim_outputs(c, fa);
     {
         ScopedTimer t(c, 0);

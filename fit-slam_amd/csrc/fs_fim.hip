@@ -155,7 +155,10 @@ __device__ __forceinline__ int voxel_part(const FsFimArgs &a, bool active, float
 // Nothing here waits for this call's own returning add, factor read or table gather: the pair (table value, count before my
 // add) is parked in `acc` and turned into info_v * exp(1 - k^0.8) by the NEXT call (resolve_pending) — for tables without
 // NaN holes (TABLE_FULL: every generated table) the gather is not waited for inside the call at all.
-template <bool TABLE_FULL>
+//
+// INFO_ONLY: the caller asked for the reference's scalar alone (isPoseSafe reads nothing else, FisherInfoManager.cpp:83-100) — the
+// 6x6 block sums and the visible count are not accumulated.
+template <bool TABLE_FULL, bool INFO_ONLY>
 __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
                                               bool active, float px, float py, float pz, Acc &acc, bool &overflow)
 {
@@ -172,7 +175,7 @@ __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *tabl
     hb &= bmask;      // whatever the hash returns, the bucket index stays inside the table
     uint4 bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
     resolve_pending<TABLE_FULL>(acc, lfac);                           // the previous call's landmarks
-    {
+    if (!INFO_ONLY) {
         const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
         const float q = (active && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f;
         const fs_f2 pxy = {px, py};
@@ -327,9 +330,19 @@ struct FimWork {
 // candidate: after the table clear and after the reduction.
 // A candidate the LDS worker cannot finish (GLOBAL_TABLE false) is appended to the work list of the HBM tier; the HBM
 // worker itself (GLOBAL_TABLE true) has nobody to hand over to and only counts such a candidate (never observed).
-// CONE1: the visibility cone is the common one (half-angle < pi/2, FsFimArgs::cone_mode == 1) — a template parameter so
-// that the test loop carries one predicate instead of a scalar dispatch over the four modes per chunk.
-template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, bool CONE1>
+// CONE: how the visibility cone enters the test loop — a template parameter, so that the loop carries ONE predicate instead of a
+// scalar dispatch over the modes per chunk.  FS_CONE_OFF: no cone (FsFimArgs::cone_mode == 0 — what the reference itself
+// requests: max_angle 4.0 > pi, FisherInfoManager.cpp:63-64), the predicate is the sign of maxd2 - n2.  FS_CONE_NARROW: the common
+// cone (half-angle < pi/2, cone_mode == 1), one v_min3.  FS_CONE_ANY: whatever cone_mode says (wide cones; the HBM tier).
+// INFO_ONLY: the call wants info_ref / n_voxels only (score_visible) — and then a landmark outside the lookup table's box
+// contributes nothing at all (a miss is skipped, FisherInfoManager.cpp:90-94), so chunks are culled EXACTLY against that box
+// in the camera frame and landmarks behind its near face are dropped by the test predicate: with the cone off this gives back
+// most of what the cone cull gave.  n_visible is not produced in this mode.
+// YAW_ONLY: every pose is a rotation about Z (the fused path builds them so, fs_raymarch.hip `yawR`): R2 = R5 = R6 = R7 = 0 and
+// R8 = 1 exactly, hence fma(R3, dy, R6 * dz) is R3 * dy and pz is dz bit for bit (up to the sign of a zero, which no
+// consumer sees) — the transform takes 7 instructions instead of 12.  The host checks the zeros before selecting it.
+enum { FS_CONE_OFF = 0, FS_CONE_NARROW = 1, FS_CONE_ANY = 2 };
+template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY>
 __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits)
 {
     constexpr uint32_t fail_code = GLOBAL_TABLE ? 3u : 2u;
@@ -415,12 +428,23 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             const float d2 = dx * dx + dy * dy + dz * dz;
             const float reach = a.max_dist_f + s.w, r2 = s.w * s.w;
             float c = fminf(reach, reach * reach - d2);               // within reach of the range sphere
-            if (CONE1 || a.cone_mode == 1) {
+            if (INFO_ONLY) {
+                // the sphere's centre in the camera frame against the table box grown by the radius (a superset of "the sphere
+                // meets the box"); the box is half a voxel wider than the outermost lattice points plus a millimetre
+                const float cx = dx * Rn[0] + dy * Rn[3] + (YAW_ONLY ? 0.0f : dz * Rn[6]);
+                const float cy = dx * Rn[1] + dy * Rn[4] + (YAW_ONLY ? 0.0f : dz * Rn[7]);
+                const float cz = YAW_ONLY ? dz : dx * Rn[2] + dy * Rn[5] + dz * Rn[8];
+                const float bx = fminf((cx + s.w) - a.box_lo[0], a.box_hi[0] - (cx - s.w));
+                const float by = fminf((cy + s.w) - a.box_lo[1], a.box_hi[1] - (cy - s.w));
+                const float bz = fminf((cz + s.w) - a.box_lo[2], a.box_hi[2] - (cz - s.w));
+                c = fminf(c, fminf(bx, fminf(by, bz)));
+            }
+            if (CONE == FS_CONE_NARROW || (CONE == FS_CONE_ANY && a.cone_mode == 1)) {
                 // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
                 // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one hardware
                 // square root; the margin dwarfs its 1-ulp error) — or the camera sits inside the sphere (|d|^2 <= r^2)
                 const float h = __builtin_amdgcn_sqrtf(fmaxf(d2 - r2, 0.0f));
-                const float dot = dx * ax + dy * ay + dz * az;
+                const float dot = YAW_ONLY ? dx * ax + dy * ay : dx * ax + dy * ay + dz * az;
                 const float lhs = dot - (a.cos_a * h - a.sin_a * s.w - (1.0e-4f * reach + 1.0e-4f));     // |d| <= reach here
                 c = fminf(c, fmaxf(lhs, r2 - d2));
             }
@@ -590,8 +614,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (skip_tier) { overflow = true; if (tid == 0) raise_overflow(); }
 
         // (vector copies: a scalar operand turns a 2-cycle multiply or subtract into a 3-cycle one — tools/valu_mix_calib.hip)
-        float maxd2_v = a.maxd2, cos2_v = a.cos2;
-        asm volatile("" : "+v"(maxd2_v), "+v"(cos2_v));
+        float maxd2_v = a.maxd2, cos2_v = a.cos2, xlo_v = a.box_lo[0];
+        asm volatile("" : "+v"(maxd2_v), "+v"(cos2_v), "+v"(xlo_v));
         Acc acc;
         acc.info = 0.f; acc.nvis = 0; acc.nvox = 0;
 #pragma unroll
@@ -624,16 +648,21 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             auto body = [&](float wx, float wy, float wz) {
                 // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
                 const float dx = wx - t[0], dy = wy - t[1], dz = wz - t[2];
-                const float px = __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
-                const float py = __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
-                const float pz = __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
+                const float px = YAW_ONLY ? __fmaf_rn(R[0], dx, R[3] * dy) : __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
+                const float py = YAW_ONLY ? __fmaf_rn(R[1], dx, R[4] * dy) : __fmaf_rn(R[1], dx, __fmaf_rn(R[4], dy, R[7] * dz));
+                const float pz = YAW_ONLY ? dz : __fmaf_rn(R[2], dx, __fmaf_rn(R[5], dy, R[8] * dz));
                 const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
                 float px2 = px * px;
                 asm("" : "+v"(px2));      // (keeps the compiler from pairing this product with cos2 * n2 in a v_pk_mul_f32 that needs two moves)
                 // The predicate is kept as ONE float whose sign decides (visible <=> m3 >= 0), so that the ballot below is the mask
                 // of a single compare — a boolean merged from several paths is materialised with a select and a second compare.
                 float m3;
-                if (CONE1) {
+                if (CONE == FS_CONE_OFF) {
+                    // no cone: the sign of maxd2 - n2 alone; INFO_ONLY also drops what lies behind the table's near face (x index
+                    // below the first lattice plane: a miss whatever y and z are)
+                    m3 = maxd2_v - n2;
+                    if (INFO_ONLY) m3 = fminf(m3, px - xlo_v);
+                } else if (CONE == FS_CONE_NARROW) {
                     // n2 <= maxd2 && px >= 0 && px2 >= cos2 * n2 in one value: the sign of a difference of two floats is exact, so each
                     // condition is "its difference is >= 0" and the three are "their minimum is >= 0" (-0.0 passes, as px >= 0 does):
                     // one v_min3_f32 and one compare instead of three compares and the scalar ANDs of their masks.
@@ -662,7 +691,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #ifdef FS_FIM_STAMPS
                         const unsigned long long ts_ = __builtin_readcyclecounter();
 #endif
-                        score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
+                        score_visible<TABLE_FULL, INFO_ONLY>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
 #ifdef FS_FIM_STAMPS
                         st[8] += __builtin_readcyclecounter() - ts_; st[9] += 1;
 #endif
@@ -712,7 +741,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // flush the queue remainder
         if (qcount > 0) {
             const bool have = lane < qcount;
-            score_visible<TABLE_FULL>(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
+            score_visible<TABLE_FULL, INFO_ONLY>(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
             qcount = 0;
         }
         if (overflow) raise_overflow();
@@ -734,17 +763,21 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
         FS_STAMP(4);
         // ---- 5. reduce: DPP within the wave, then across waves through LDS
-        float vals[FS_NACC];
+        // (INFO_ONLY: three quantities instead of eighteen — info, landmarks scored, voxels)
+        constexpr int NRED = INFO_ONLY ? 3 : FS_NACC;
+        float vals[NRED];
         vals[0] = acc.info;
+        if (!INFO_ONLY) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { vals[1 + i] = acc.AB[i].x; vals[7 + i] = acc.AB[i].y; }
-        vals[13] = acc.s01.x; vals[14] = acc.s01.y; vals[15] = acc.s2;
-        vals[16] = (float)acc.nvis;     // exact: < 2^24 per lane
-        vals[17] = (float)acc.nvox;
+            for (int i = 0; i < 6; ++i) { vals[1 + i] = acc.AB[i].x; vals[7 + i] = acc.AB[i].y; }
+            vals[13] = acc.s01.x; vals[14] = acc.s01.y; vals[15] = acc.s2;
+        }
+        vals[NRED - 2] = (float)acc.nvis;     // exact: < 2^24 per lane
+        vals[NRED - 1] = (float)acc.nvox;
         wave_sums_dpp(vals);
         if (lane == 63) {
 #pragma unroll
-            for (int i = 0; i < FS_NACC; ++i) sh_red[i * WAVES + wave] = vals[i];     // [quantity][wave]: one thread reads its row with wide loads
+            for (int i = 0; i < NRED; ++i) sh_red[i * WAVES + wave] = vals[i];     // [quantity][wave]: one thread reads its row with wide loads
         }
         FS_STAMP(5);
         __syncthreads();
@@ -755,14 +788,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // (the sums by the first lanes of wave 1, the flags and counters below by thread 0: the two halves of the epilogue run side
         // by side instead of one after the other on wave 0, which everybody waits for at the next barrier)
         int qi = tid - (WAVES > 1 ? 64 : 0);
-        if (qi >= 0 && qi < FS_NACC && !failed) {
+        if (qi >= 0 && qi < NRED && !failed) {
             float part[WAVES];
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) part[w] = sh_red[qi * WAVES + w];
             double x = 0.0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) x += (double)part[w];
-            if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + qi] = x;
+            const int q_out = (INFO_ONLY && qi > 0) ? FS_NACC - NRED + qi : qi;     // info stays sum 0, the two counts sums 16 and 17
+            if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + q_out] = x;
         }
         if (tid == 0) {
             // tier that must re-score the candidate (0: done) | chunks scanned per pass << 4 (the finish kernel's voxel ratio)
@@ -807,13 +841,13 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
 // LDS tier: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
 // (two workgroups of 8 waves per CU = 4 waves per SIMD: the register allocator must stay within 128 VGPRs)
-template <int THREADS, bool TABLE_FULL, bool CONE1>
+template <int THREADS, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FS_T1_WAVES_PER_EU)))
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
-    fim_worker<THREADS, false, TABLE_FULL, CONE1>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits);
+    fim_worker<THREADS, false, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits);
 }
 
 // HBM tier: candidates the LDS tier appended to its work list; table in HBM with 2x the landmark count of slots and
@@ -825,7 +859,7 @@ void fs_fim_tier3_kernel(const FsFimArgs a)
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.flagged, 0, (int)a.counters[2], a.counters + 9};
     uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
-    fim_worker<THREADS, true, TABLE_FULL, false>(a, work, fs_fim_lds, table, a.ghash_bits);
+    fim_worker<THREADS, true, TABLE_FULL, FS_CONE_ANY, false, false>(a, work, fs_fim_lds, table, a.ghash_bits);
 }
 
 // One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
@@ -861,6 +895,12 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
         a.counters[1] = 0ull; a.counters[2] = 0ull; a.counters[3] = 0ull; a.counters[7] = 0ull; a.counters[8] = 0ull; a.counters[9] = 0ull;
     }
     if (c >= a.n) return;
+    if (a.info_only) {                                       // isPoseSafe's scalar and the voxel count: nothing else was accumulated
+        const double *S1 = a.sums + (size_t)c * FS_NACC;
+        a.info_ref[c] = (float)S1[0];
+        a.n_voxels[c] = (int)(S1[17] + 0.5);
+        return;
+    }
     const double *S = a.sums + (size_t)c * FS_NACC;
     const double *A = S + 1, *B = S + 7, *Sv = S + 13;
     // F = [[ B , -[s]x ], [ [s]x , A ]]   (block form of sum_k F(p_k))
@@ -971,14 +1011,14 @@ hipError_t allow_lds(K kernel, size_t bytes)
 
 namespace {
 
-template <bool TABLE_FULL, bool CONE1>
+template <bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY>
 hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
 {
     const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
-    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, CONE1>;
+    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY>;
     hipError_t e = allow_lds(kernel, lds);
     if (e != hipSuccess) return e;
-    static int resident = 0;                                   // same kernel, same LDS budget class: query once
+    static int resident = 0;                                   // same kernel, same LDS budget class: query once (per instantiation)
     static size_t resident_lds = 0;
     if (resident == 0 || resident_lds != lds) { resident = resident_blocks(kernel, FS_T1_THREADS, lds); resident_lds = lds; }
     hipLaunchKernelGGL(kernel, dim3(a.cand_count < resident ? a.cand_count : resident), dim3(FS_T1_THREADS), lds, s, a);
@@ -1003,8 +1043,20 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
     if (a0.n <= 0 || a0.cand_count <= 0) return hipSuccess;
     FsFimArgs a = a0;
-    if (a.cone_mode == 1) return a.table_full ? launch_tier1<true, true>(a, s) : launch_tier1<false, true>(a, s);
-    return a.table_full ? launch_tier1<true, false>(a, s) : launch_tier1<false, false>(a, s);
+    const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
+    // The specialised workers exist for finite tables (every generated one) and the two common cone modes; anything else runs the
+    // general worker, which computes a superset (the finish kernel then hands out what was asked for).
+    const bool special = a.table_full && cone != FS_CONE_ANY;
+    if (!special || (!a.info_only && !a.yaw_only)) {
+        if (cone == FS_CONE_OFF) return a.table_full ? launch_tier1<true, FS_CONE_OFF, false, false>(a, s) : launch_tier1<false, FS_CONE_OFF, false, false>(a, s);
+        if (cone == FS_CONE_NARROW) return a.table_full ? launch_tier1<true, FS_CONE_NARROW, false, false>(a, s) : launch_tier1<false, FS_CONE_NARROW, false, false>(a, s);
+        return a.table_full ? launch_tier1<true, FS_CONE_ANY, false, false>(a, s) : launch_tier1<false, FS_CONE_ANY, false, false>(a, s);
+    }
+    if (a.info_only) {
+        if (a.yaw_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, true>(a, s);
+        return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false>(a, s);
+    }
+    return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, true>(a, s);
 }
 
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a0, int pool, hipStream_t s)

@@ -154,6 +154,10 @@ struct FsFimArgs {
     float cos2;                // c*c, c = (float)cos(max_angle)
     int32_t cone_mode;         // 0 disabled, 1 c >= 0 (cone also culled per chunk), 2 c < 0, 3 c >= 0 but too wide to cull
     float max_dist_f, cos_a, sin_a;   // chunk culling (cone culled only in mode 1)
+    // specialised workers (fs_fim.hip): info_only — the call reads info_ref / n_voxels only (fs_score_fim with NULL for the other
+    // columns: what isPoseSafe needs); yaw_only — every pose record is a rotation about Z (checked on the host)
+    int32_t info_only, yaw_only;
+    float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;
     const float *Rt;
