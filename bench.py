@@ -92,6 +92,10 @@ def launcher_command(args, argv, port=None):
 def launch_ranks(args, argv) -> int:
     """--gpus N > 1 without a launcher around us: start N fresh ranks and relay rank 0's line.  This process has not
     initialised the GPU (no torch.cuda call, no HIP library loaded) and never does."""
+    if not args.dry_run:
+        # build (or find up to date) the HIP library HERE, once, before the ranks exist: hipcc needs no GPU, the build takes an
+        # exclusive lock, and the ranks' own load_library() then finds the content stamp matching and compiles nothing
+        importlib.import_module("fit-slam_amd._build").build()
     cmd = launcher_command(args, argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -151,6 +155,45 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def compare_records(r, arr, fim, fim_angle):
+    """GPU records against the oracle's arrival / pose information of the same candidates."""
+    n_s = int(r.shape[0])
+    ok = arr["status"] == 0
+    ints = (np.array_equal(r["arrival"], arr["arrival"]) and np.array_equal(r["argmax"], arr["argmax"]) and
+            np.array_equal((r["flags"] >> 8) & 0xFF, arr["status"]) and
+            np.array_equal(r["flags"] & 1, arr["achievable"]) and
+            np.array_equal(r["n_visible"][ok], fim["n_visible"][ok]) and
+            np.array_equal(((r["flags"] >> 16) & 0xFFFF)[ok], np.minimum(fim["n_voxels"][ok], 65535)))
+    sc = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
+    e_info = float(np.max(np.abs(r["info_ref"][ok] - fim["info_f64"][ok]) / sc)) if ok.any() else 0.0
+    e_tr = float(np.max(np.abs(r["trace"][ok] - fim["trace"][ok]) / np.maximum(fim["trace"][ok], 1e-6))) if ok.any() else 0.0
+    # D-optimality: no reference counterpart (the reference keeps the trace only) — against the float64 oracle, relative to
+    # max(1, |log det|), over the candidates where both are finite; the share within north_star's 1e-4 is reported
+    fin = ok & np.isfinite(fim["logdet"]) & np.isfinite(r["logdet"])
+    e_ld = np.abs(r["logdet"][fin] - fim["logdet"][fin]) / np.maximum(1.0, np.abs(fim["logdet"][fin]))
+    same_sing = bool(np.array_equal(np.isfinite(r["logdet"][ok]), np.isfinite(fim["logdet"][ok])))
+    return {"n": n_s, "integers_bit_exact": bool(ints), "info_max_rel_err": e_info, "trace_max_rel_err": e_tr,
+            "logdet_max_rel_err": float(e_ld.max()) if e_ld.size else 0.0,
+            "logdet_share_within_1e-4": float(np.mean(e_ld <= 1e-4)) if e_ld.size else 1.0,
+            "logdet_finite_candidates": int(fin.sum()), "logdet_singularity_agrees": same_sing,
+            "visibility": f"14 m, {fim_angle} rad",
+            "ok": bool(ints and e_info <= 1e-4 and e_tr <= 1e-4 and (e_ld.size == 0 or e_ld.max() <= 1e-4))}
+
+
+def sample_parity(w, arrival_kw, mx, goals, fsize, black, rec, fim_angle, where):
+    """N > 1: a sample spread over every rank's block, scored by the oracle on rank 0's host cores (outside every timed region)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O   # the checker
+    O.build()
+    T = min(16, os.cpu_count() or 1)
+    G = O.Grid(w.cells, origin=w.origin, resolution=w.resolution)
+    arr = O.arrival_information(G, O.RayParams(**arrival_kw), goals, fsize, black, min_gt=mx["min_gt"], faithful=False, n_threads=T, want_ray_counts=False)
+    fim = O.pose_information(O.Table.generate(), w.landmarks, O.poses_from_yaw(goals, arr["yaw"]), 14.0, fim_angle, n_threads=T, want_f64=True)
+    out = compare_records(rec, arr, fim, fim_angle)
+    out["sample"] = where
+    return out
+
+
 def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx, fim_angle=1.0):
     """Time the oracle (kind 'port') on a bounded sample of the same workload, single thread, three runs (median), and
     gate the GPU records of that sample against it."""
@@ -191,29 +234,7 @@ def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx, fim_angle=1.0):
     dt_o, _, _ = run(0, n_o, cores, False)
     out["omp_value"] = n_o / dt_o
     out["omp_cores"] = cores
-    parity = None
-    if gpu_rec is not None:
-        r = gpu_rec[:n_s]
-        ok = arr["status"] == 0
-        ints = (np.array_equal(r["arrival"], arr["arrival"]) and np.array_equal(r["argmax"], arr["argmax"]) and
-                np.array_equal((r["flags"] >> 8) & 0xFF, arr["status"]) and
-                np.array_equal(r["flags"] & 1, arr["achievable"]) and
-                np.array_equal(r["n_visible"][ok], fim["n_visible"][ok]))
-        sc = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
-        e_info = float(np.max(np.abs(r["info_ref"][ok] - fim["info_f64"][ok]) / sc)) if ok.any() else 0.0
-        e_tr = float(np.max(np.abs(r["trace"][ok] - fim["trace"][ok]) / np.maximum(fim["trace"][ok], 1e-6))) if ok.any() else 0.0
-        # D-optimality: no reference counterpart (the reference keeps the trace only) — against the float64 oracle, relative to
-        # max(1, |log det|), over the candidates where both are finite; the share within north_star's 1e-4 is reported
-        fin = ok & np.isfinite(fim["logdet"]) & np.isfinite(r["logdet"])
-        e_ld = np.abs(r["logdet"][fin] - fim["logdet"][fin]) / np.maximum(1.0, np.abs(fim["logdet"][fin]))
-        same_sing = bool(np.array_equal(np.isfinite(r["logdet"][ok]), np.isfinite(fim["logdet"][ok])))
-        parity = {"n": int(n_s), "integers_bit_exact": bool(ints), "info_max_rel_err": e_info,
-                  "trace_max_rel_err": e_tr,
-                  "logdet_max_rel_err": float(e_ld.max()) if e_ld.size else 0.0,
-                  "logdet_share_within_1e-4": float(np.mean(e_ld <= 1e-4)) if e_ld.size else 1.0,
-                  "logdet_finite_candidates": int(fin.sum()), "logdet_singularity_agrees": same_sing,
-                  "visibility": f"14 m, {fim_angle} rad",
-                  "ok": bool(ints and e_info <= 1e-4 and e_tr <= 1e-4 and (e_ld.size == 0 or e_ld.max() <= 1e-4))}
+    parity = compare_records(gpu_rec[:n_s], arr, fim, fim_angle) if gpu_rec is not None else None
     return out, parity
 
 
@@ -473,14 +494,21 @@ def run_rank(args) -> int:
         n_total = cfg["n_cand"]
         w = fs.synth.make_workload(wl_name)
     else:
+        # every rank builds the same map and cloud (they are replicated) and ONLY its own block of the n x world list:
+        # block r of the list is a function of (config, r) (synth.candidate_block; block 0 = the N = 1 list)
         wl_name = args.workload
         cfg = fs.synth.CONFIGS[wl_name]
         n_total = cfg["n_cand"] * world
-        w = fs.synth.make_workload(wl_name, n_cand=n_total)
+        w = fs.synth.make_workload(wl_name)
     if args.depth_cells > 0:
         w.max_camera_depth = args.depth_cells * w.resolution
     lo, hi = shard.shard_bounds(n_total, world, rank)
     cap = shard.shard_capacity(n_total, world)
+    if args.scaling == "strong":
+        blk_goals, blk_fsize, blk_black = w.goals[lo:hi], w.frontier_size[lo:hi], w.blacklisted[lo:hi]
+    else:
+        assert (lo, hi) == (rank * cfg["n_cand"], (rank + 1) * cfg["n_cand"])
+        blk_goals, blk_fsize, blk_black = fs.synth.candidate_block(w, wl_name, rank)
 
     # Explicit streams for everything: a scorer launches on the stream handle it is given and torch (and RCCL's
     # all-gather) orders its work after the CURRENT stream — so a batch is issued with its scorer's stream current, and
@@ -520,9 +548,9 @@ def run_rank(args) -> int:
     mx = sc.max_arrival()
 
     # candidate columns of this rank's block, resident in HBM
-    d_goal = torch.from_numpy(w.goals[lo:hi].copy()).to(dev)
-    d_fsize = torch.from_numpy(w.frontier_size[lo:hi].copy()).to(dev)
-    d_black = torch.from_numpy(w.blacklisted[lo:hi].copy()).to(dev)
+    d_goal = torch.from_numpy(np.ascontiguousarray(blk_goals)).to(dev)
+    d_fsize = torch.from_numpy(np.ascontiguousarray(blk_fsize)).to(dev)
+    d_black = torch.from_numpy(np.ascontiguousarray(blk_black)).to(dev)
     # two record buffers per context: the all-gather of a batch runs on the communicator's stream while the next batch of
     # the same context is being scored
     n_buf = 2 * n_pipe
@@ -552,13 +580,17 @@ def run_rank(args) -> int:
         return state["full"]
 
     def fence():
+        """barrier + synchronise; returns the moment THIS rank had finished its own work (before it met the others)"""
         for b in range(n_buf):
             if pending[b] is not None:
                 pending[b].wait()
                 pending[b] = None
+        torch.cuda.synchronize(dev)                                  # every stream of the device
+        t_ready = time.perf_counter()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)                                  # every stream of the device
+            torch.cuda.synchronize(dev)
+        return t_ready
 
     for _ in range(args.warmup):
         step()
@@ -569,7 +601,7 @@ def run_rank(args) -> int:
     # them: the roofline's launch durations come from that block, `value` from the median block (an event-free one
     # whenever --repeats >= 3).  All blocks are listed in "timing".
     n_rep = max(1, args.repeats)
-    block_s = []
+    block_s, local_s = [], []
     full = None
     for r in range(n_rep):
         if r == n_rep - 1:
@@ -581,8 +613,9 @@ def run_rank(args) -> int:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             full = step()
-        fence()
+        t_ready = fence()
         block_s.append(time.perf_counter() - t0)
+        local_s.append(t_ready - t0)                                 # this rank alone: its steps + its share of the gathers
     n_steps_all = args.steps * len(block_s)
     n_steps_ev = args.steps                                          # steps of the block that carried the events
 
@@ -612,7 +645,7 @@ def run_rank(args) -> int:
     #    predecessor recorded nothing (option sort.costmap off for one call) sees the empty map of a first call on a new snapshot.
     extra = {}
     if world == 1 and not args.no_parity:
-        g_h, f_h, b_h = w.goals[lo:hi], w.frontier_size[lo:hi], w.blacklisted[lo:hi]
+        g_h, f_h, b_h = blk_goals, blk_fsize, blk_black
         for _ in range(3):
             sc.score_candidates(g_h, f_h, b_h)
         t0 = time.perf_counter()
@@ -658,10 +691,91 @@ def run_rank(args) -> int:
         extra["reference_request_visibility" if args.fim_angle < np.pi else "build_cone_visibility"] = other_visibility(
             args, sc, w, n_local, d_goal, d_fsize, d_black, torch.zeros_like(d_recs[0]), dev, mx, arrival_kw)
 
+    # ---- ranked step: the scoring step followed, on the same stream and without the records visiting the host, by
+    # fs_rank_candidates_dev over the full (gathered) list — "scored / ranked candidates out".  Path lengths are an input of the
+    # reference's ranking (its planner supplies them, DEP/src/FrontierCostsManager.cpp:103-117): resident columns here, the
+    # straight-line distance from the map's centre and the bearing as heading.  One block of K steps, same bracketing; reported
+    # next to `value`, never instead of it.  (Path columns: see below.)
+    ranked = None
+    if world == 1 or args.backend == "nccl":
+        # (a function of the list index alone — a low-discrepancy sequence over [0.5, 30] m and [0, pi] rad — so that no rank
+        # needs the other ranks' goal points and the columns are the same at every N)
+        idx = np.arange(n_total, dtype=np.float64)
+        d_len = torch.from_numpy(0.5 + 29.5 * np.modf(idx * 0.6180339887498949)[0]).to(dev)
+        d_head = torch.from_numpy(np.pi * np.modf(idx * 0.7548776662466927)[0]).to(dev)
+        d_cost = torch.zeros(n_total, dtype=torch.float64, device=dev)
+        d_order = torch.zeros(n_total, dtype=torch.int32, device=dev)
+        d_rerr = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def ranked_step():
+            full_ = step()
+            k = state["k"] - 1
+            c, b = k % n_pipe, k % n_buf
+            with torch.cuda.stream(streams[c]):
+                if pending[b] is not None:
+                    pending[b].wait()                                # the ranking reads the gathered list
+                    pending[b] = None
+                scs[c].rank_candidates_dev(n_total, full_.data_ptr(), d_len.data_ptr(), d_head.data_ptr(), d_cost.data_ptr(),
+                                           d_order=d_order.data_ptr(), d_err=d_rerr.data_ptr())
+
+        for _ in range(max(2, args.warmup)):
+            ranked_step()
+        for c in scs:
+            c.enable_kernel_timing(True)
+            c.kernel_time(3)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ranked_step()
+        fence()
+        dt_r = time.perf_counter() - t0
+        rank_ms, rank_n = kernel_sum(3)
+        for c in scs:
+            c.enable_kernel_timing(False)
+            for kind in range(5):
+                c.kernel_time(kind)
+        order = d_order.cpu().numpy()
+        cost = d_cost.cpu().numpy()
+        ranked = {"dt": dt_r, "rank_kernels_ms_per_step": rank_ms / max(rank_n, 1), "range_error": int(d_rerr.cpu()[0]),
+                  "order_is_a_permutation": bool(np.array_equal(np.sort(order), np.arange(n_total))),
+                  "costs_ascending": bool(np.all(np.diff(cost[order]) >= 0))}
+
+    # ---- what a sub-linear curve would be made of (N > 1): every rank's own time per step, the spread with which the ranks
+    # reach the closing barrier, and the all-gather by itself (blocking calls between an event pair on the scorer's stream)
+    multi = None
     if world > 1:
-        tmax = torch.tensor(block_s, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        red_dev = dev if args.backend == "nccl" else "cpu"
+        tmax = torch.tensor(block_s + ([ranked["dt"]] if ranked else []), dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        block_s = [float(x) for x in tmax.tolist()]
+        vals = [float(x) for x in tmax.tolist()]
+        block_s = vals[:len(block_s)]
+        if ranked:
+            ranked["dt"] = vals[-1]
+        mine = torch.tensor(local_s, dtype=torch.float64, device=red_dev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        loc = np.array([[float(x) for x in t.tolist()] for t in everyone])        # [rank][block], seconds
+        gather_ms = None
+        if args.backend == "nccl":
+            with torch.cuda.stream(streams[0]):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(5):
+                    shard.gather_records(d_recs[0], n_total)
+                e0.record()
+                for _ in range(20):
+                    shard.gather_records(d_recs[0], n_total)
+                e1.record()
+            torch.cuda.synchronize(dev)
+            g = torch.tensor([e0.elapsed_time(e1) / 20], dtype=torch.float64, device=dev)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            gather_ms = float(g[0])
+        multi = {"per_rank_ms_per_step": [float(np.median(loc[r]) / args.steps * 1e3) for r in range(world)],
+                 "per_rank_ms_per_step_min": float(np.median(loc, axis=1).min() / args.steps * 1e3),
+                 "per_rank_ms_per_step_max": float(np.median(loc, axis=1).max() / args.steps * 1e3),
+                 "barrier_skew_ms": float(np.median(loc.max(axis=0) - loc.min(axis=0)) * 1e3),
+                 "barrier_skew_note": "per timed block: last rank ready minus first rank ready (each after its own K steps and gathers), median over the blocks",
+                 "all_gather_ms": gather_ms,
+                 "all_gather_note": f"one blocking all_gather_into_tensor of {n_total} x 32 B between an event pair on the scorer's stream, mean of 20, max over ranks (nccl backend only)"}
 
     if rank == 0:
         dt = float(np.median(block_s))
@@ -684,6 +798,22 @@ def run_rank(args) -> int:
         cpu, parity = (None, None)
         if world == 1 and args.cpu_seconds > 0:
             cpu, parity = cpu_baseline(w, arrival_kw, n_total, args.cpu_seconds, gpu_rec, mx, args.fim_angle)
+        elif world > 1 and gpu_rec is not None:
+            # no CPU baseline at N > 1 (rank 0, N = 1 only), but the gathered list is still gated: 96 candidates out of every
+            # rank's block against the oracle
+            per_blk = 96
+            gs, fz, bl, ix = [], [], [], []
+            for r in range(world):
+                b_lo, b_hi = shard.shard_bounds(n_total, world, r)
+                pick = np.unique(np.linspace(0, max(b_hi - b_lo - 1, 0), num=min(per_blk, b_hi - b_lo)).astype(np.int64))
+                if args.scaling == "strong":
+                    g_, f_, k_ = w.goals[b_lo:b_hi], w.frontier_size[b_lo:b_hi], w.blacklisted[b_lo:b_hi]
+                else:
+                    g_, f_, k_ = (blk_goals, blk_fsize, blk_black) if r == rank else fs.synth.candidate_block(w, wl_name, r)
+                gs.append(g_[pick]); fz.append(f_[pick]); bl.append(k_[pick]); ix.append(b_lo + pick)
+            ix = np.concatenate(ix)
+            parity = sample_parity(w, arrival_kw, mx, np.concatenate(gs), np.concatenate(fz), np.concatenate(bl), gpu_rec[ix],
+                                   args.fim_angle, f"{per_blk} candidates evenly spaced in each of the {world} rank blocks")
         per_rank = n_total // world if args.scaling == "strong" else cfg["n_cand"]
         roofline = {
             # the roofline the fraction below is priced against: the HBM one the metric asks for (algorithmic bytes / time / 8 TB/s).
@@ -730,6 +860,12 @@ def run_rank(args) -> int:
                                     "from": "the last timed block (the only one with per-kernel hipEvents); with --pipeline > 1 "
                                             "a kernel's duration includes the time it shares the chip with the other stream's kernels"},
             "cpu_baseline": cpu, "parity": parity,
+            "ranked_step": ({"ms_per_step": ranked["dt"] / args.steps * 1e3, "candidate_goals_per_s": n_total * args.steps / ranked["dt"],
+                             "rank_kernels_ms_per_step": ranked["rank_kernels_ms_per_step"], "range_error": ranked["range_error"],
+                             "order_is_a_permutation": ranked["order_is_a_permutation"], "costs_ascending": ranked["costs_ascending"],
+                             "note": "score (+ all-gather) + fs_rank_candidates_dev over the full list on the same stream, path columns resident; "
+                                     "one block of K steps; never `value`"} if ranked else None),
+            "multi_gpu": multi,
             "other_operating_points": extra or None,
         }
         print(json.dumps(line), flush=True)

@@ -66,12 +66,28 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built (there is no CPU fallback)")
 
 
+STAMP = LIB + ".stamp"
+
+
+def source_digest() -> str:
+    """What the library was built from: SHA-256 over the sources, the headers and the compiler flags."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for name in SOURCES + HEADERS:
+        h.update(name.encode())
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    """By CONTENT, not by modification time: a copy of the tree (the GPU box's snapshot, a fresh checkout next to a built
+    library) may order the timestamps any way it likes — N ranks starting there must not all decide to rebuild."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(STAMP).read().strip() != source_digest()
+    except OSError:
+        return True
 
 
 def _parse_resource_remarks(text: str) -> dict:
@@ -111,14 +127,29 @@ def _record_resources(src: str, usage: dict) -> None:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile what is out of date and link.  Safe to call from several processes at once (N ranks of one launcher, pytest-xdist
+    workers): the work happens under an exclusive lock on the source directory, and whoever gets the lock second finds the
+    library up to date and returns."""
     if not force and not needs_build():
         return LIB
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():       # another process built it while this one waited
+                return LIB
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     cc = hipcc()
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", SUFFIX + ".o"))
         src_path = os.path.join(CSRC, src)
-        hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+        hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)])
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src_path), hdr_t):
             cmd = [cc, *HIPCC_FLAGS, "-c", src_path, "-o", obj]
             if verbose:
@@ -132,10 +163,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 raise subprocess.CalledProcessError(res.returncode, cmd)
             _record_resources(src, usage)
         objs.append(obj)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    # linked under a temporary name and renamed into place: a process that loads the library while another one links never
+    # sees a half-written file
+    tmp = LIB + f".tmp{os.getpid()}"
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.check_call(cmd, stdout=sys.stderr)
+    os.replace(tmp, LIB)
+    with open(STAMP + f".tmp{os.getpid()}", "w") as f:
+        f.write(source_digest() + "\n")
+    os.replace(STAMP + f".tmp{os.getpid()}", STAMP)
     return LIB
 
 

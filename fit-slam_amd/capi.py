@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim", "fs_information_frontier_pair",
     "fs_upload_keyframes", "fs_information_for_pose",
-    "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_selftest_fp64",
+    "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_rank_candidates_dev", "fs_selftest_fp64",
     "fs_multi_create", "fs_multi_destroy", "fs_multi_num_devices", "fs_multi_ctx", "fs_multi_last_error", "fs_multi_shard_bounds",
     "fs_multi_set_option", "fs_multi_set_ray_params", "fs_multi_upload_grid", "fs_multi_upload_landmarks", "fs_multi_lookup_generate",
     "fs_multi_lookup_load", "fs_multi_set_fim_params", "fs_multi_max_arrival", "fs_multi_score_arrival", "fs_multi_score_candidates",
@@ -122,6 +122,7 @@ def load_library(build: bool = True):
     L.fs_score_candidates.argtypes = [vp, i32] + [vp] * 5
     L.fs_score_candidates_dev.argtypes = [vp, i32] + [vp] * 5
     L.fs_rank_candidates.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp]
+    L.fs_rank_candidates_dev.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp, vp]
     L.fs_selftest_fp64.argtypes = [vp, i32, C.POINTER(i64)]
     L.fs_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.fs_multi_destroy.argtypes = [vp]
@@ -393,6 +394,14 @@ class FrontierScorer:
         self._check(self._L.fs_rank_candidates(self._h, n, _p(rec), _p(bl), _p(pl), _p(ph), alpha, beta, max_vx, max_wz,
                                                _p(cost), _p(au), _p(du), _p(order)))
         return dict(weighted_cost=cost, arrival_utility=au, distance_utility=du, order=order)
+
+    def rank_candidates_dev(self, n, d_records, d_path_length, d_path_heading, d_cost, d_au=0, d_du=0, d_order=0, d_black=0,
+                            d_err=0, alpha=0.25, beta=1.0, max_vx=0.5, max_wz=0.5):
+        """Device-pointer form (ints from tensor.data_ptr()); asynchronous on the context's stream."""
+        vp = C.c_void_p
+        o = lambda p: vp(p) if p else None
+        self._check(self._L.fs_rank_candidates_dev(self._h, int(n), vp(d_records), o(d_black), vp(d_path_length), vp(d_path_heading),
+                                                   alpha, beta, max_vx, max_wz, vp(d_cost), o(d_au), o(d_du), o(d_order), o(d_err)))
 
     def selftest_fp64(self, max_abs=256) -> int:
         bad = C.c_int64()

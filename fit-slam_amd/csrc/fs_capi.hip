@@ -102,6 +102,7 @@ struct fs_ctx {
     int32_t m = 0, n_chunks = 0;
     DevBuf<float> d_lx, d_ly, d_lz, d_spheres;
     bool opt_cull = true;
+    bool opt_learn = true;         // "fim.learn": the pass prediction uses the voxel ratio finished calls have shown (0: the fixed cap only — results then do not depend on the calls a context has served before)
     bool opt_special = true;       // "fim.specialise": the INFO_ONLY / YAW_ONLY workers where they apply (0: always the general worker)
     bool yaw_exact = false;        // every rotation of d_yawR is about Z with exact zeros / one (what YAW_ONLY relies on)
     int opt_bits1 = 14;            // development knobs (fs_set_option "fim.bits1", "fim.skip32")
@@ -154,6 +155,9 @@ struct fs_ctx {
     PinnedBuf h_in, h_out;         // staging of the per-call candidate columns / of the records
     DevBuf<char> d_in;             // the candidate columns of the host-buffer entry points, packed as in h_in
     const double *in_goal = nullptr; const int32_t *in_fsize = nullptr; const uint8_t *in_black = nullptr, *in_achin = nullptr;
+    // fs_score_arrival_begin -> _end: where the columns waiting in h_out go (caller's arrays) once the stream has drained
+    struct PendingCol { void *host; size_t off, bytes; };
+    std::vector<PendingCol> arrival_pending;
     // scratch of the per-tick entry points (fs_trace_segments, fs_frontier_cells, fs_information_frontier_pair,
     // fs_upload_grid_bricks): owned by the context and grown on demand, never allocated and freed per call
     DevBuf<double> d_seg_start, d_seg_end, d_tri;
@@ -418,7 +422,10 @@ bool use_class_walk(const fs_ctx *c, double max_length_cells)
 {
     // (the walk forms brick addresses with 24-bit multiplies: the largest brick stride, 512 * bricks_x * bricks_y, must fit)
     const uint64_t stride = 512ull * (uint64_t)((c->nx + 7) >> 3) * (uint64_t)((c->ny + 7) >> 3);
-    if (c->opt_layout == 1 || stride >= (1ull << 24)) return false;
+    // (... and it forms the cell address A in 32 bits: a grid thin in x / y and deep in z can pass the 2^31-cell limit and still
+    // pad to 2^32 class cells or more — 4 x 4 x 2^26 does; such a grid keeps the byte walk)
+    const uint64_t padded_cells = stride * (uint64_t)((c->nz + 7) >> 3);
+    if (c->opt_layout == 1 || stride >= (1ull << 24) || padded_cells >= (1ull << 32)) return false;
     if (c->opt_layout == 2) return true;
     return c->nz > 1 || max_length_cells >= FS_CLASS_WALK_FROM;
 }
@@ -537,6 +544,7 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
         }
     }
     a.info_only = 0; a.yaw_only = 0;
+    a.learn = c->opt_learn ? 1 : 0;
     a.hash_bits = bits;
     a.skip32 = c->opt_skip32;
     a.gtable = c->d_gtable.p;
@@ -1027,21 +1035,36 @@ int fs_score_arrival_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const i
         ScopedTimer t(c, 0);
         FS_HIP(c, fs_launch_raymarch(a, c->stream));
     }
-    if (ray_counts) FS_HIP(c, hipMemcpyAsync(ray_counts, c->d_raycounts.p, sizeof(int32_t) * (size_t)n * per, hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipMemcpyAsync(arrival, c->d_arrival.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipMemcpyAsync(argmax, c->d_argmax.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipMemcpyAsync(status, c->d_status.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipMemcpyAsync(yaw, c->d_yaw.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipMemcpyAsync(achievable, c->d_ach.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    // The columns come back through the context's page-locked buffer: a copy into the caller's pageable arrays (std::vector in
+    // the ROS adapter, numpy in the binding) would make every one of these calls host-synchronous — `begin` would return only
+    // when this device is done, and fs_multi_score_arrival would run its devices one after the other.
+    struct Col { void *host; const void *dev; size_t bytes; };
+    const size_t nn = (size_t)n;
+    const Col cols[6] = {{ray_counts, c->d_raycounts.p, 4 * nn * per}, {arrival, c->d_arrival.p, 4 * nn}, {argmax, c->d_argmax.p, 4 * nn},
+                         {status, c->d_status.p, 4 * nn}, {yaw, c->d_yaw.p, 8 * nn}, {achievable, c->d_ach.p, nn}};
+    size_t total = 0;
+    for (const Col &col : cols) if (col.host) total += (col.bytes + 15) & ~(size_t)15;
+    FS_HIP(c, c->h_out.ensure(total));
+    c->arrival_pending.clear();
+    size_t off = 0;
+    for (const Col &col : cols) {
+        if (!col.host) continue;
+        FS_HIP(c, hipMemcpyAsync(c->h_out.p + off, col.dev, col.bytes, hipMemcpyDeviceToHost, c->stream));
+        c->arrival_pending.push_back({col.host, off, col.bytes});
+        off += (col.bytes + 15) & ~(size_t)15;
+    }
     return FS_OK;
 }
 
-// ... and waited for here
+// ... and waited for here: one synchronisation, then the columns go to the caller's arrays
 int fs_score_arrival_end(fs_ctx *c)
 {
     if (!c) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    FS_HIP(c, hipStreamSynchronize(c->stream));
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { c->arrival_pending.clear(); return fail(c, FS_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+    for (const fs_ctx::PendingCol &col : c->arrival_pending) std::memcpy(col.host, c->h_out.p + col.off, col.bytes);
+    c->arrival_pending.clear();
     return FS_OK;
 }
 
@@ -1214,6 +1237,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.specialise") == 0) { c->opt_special = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "fim.learn") == 0) { c->opt_learn = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
@@ -1648,6 +1672,30 @@ int fs_score_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int3
 
 // ------------------------------------------------------------------ utility + ranking
 
+int fs_rank_candidates_dev(fs_ctx *c, int32_t n, const fs_record *d_records, const uint8_t *d_blacklisted,
+                           const double *d_path_length, const double *d_path_heading,
+                           double alpha, double beta, double max_vx, double max_wz,
+                           double *d_weighted_cost, double *d_arrival_utility, double *d_distance_utility,
+                           int32_t *d_order, int32_t *d_range_error)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (n < 0 || (n > 0 && (!d_records || !d_path_length || !d_path_heading || !d_weighted_cost))) return fail(c, FS_E_INVALID, "null device pointer");
+    if (n == 0) return FS_OK;
+    // columns the caller does not want still have to be written somewhere: the context's own scratch
+    if (!d_arrival_utility) { FS_HIP(c, c->d_au.ensure(n)); d_arrival_utility = c->d_au.p; }
+    if (!d_distance_utility) { FS_HIP(c, c->d_du.ensure(n)); d_distance_utility = c->d_du.p; }
+    if (!d_order) { FS_HIP(c, c->d_order.ensure(n)); d_order = c->d_order.p; }
+    if (!d_range_error) { FS_HIP(c, c->d_err.ensure(1)); d_range_error = c->d_err.p; }
+    ScopedTimer t(c, 3);
+    FS_HIP(c, fs_launch_rank(n, d_records, d_blacklisted, d_path_length, d_path_heading, alpha, beta, max_vx, max_wz, c->max_gt,
+                             d_weighted_cost, d_arrival_utility, d_distance_utility, d_order, d_range_error,
+                             &c->rank_scratch, &c->rank_scratch_bytes, c->stream));
+    return FS_OK;
+}
+
+// The host-buffer form: one packed transfer in through the context's page-locked buffer, fs_rank_candidates_dev on the
+// context's own device columns, the requested columns back through the other page-locked buffer, ONE synchronisation.
 int fs_rank_candidates(fs_ctx *c, int32_t n, const fs_record *records, const uint8_t *blacklisted,
                        const double *path_length, const double *path_heading,
                        double alpha, double beta, double max_vx, double max_wz,
@@ -1658,29 +1706,45 @@ int fs_rank_candidates(fs_ctx *c, int32_t n, const fs_record *records, const uin
     FS_HIP(c, hipSetDevice(c->device));
     if (n < 0 || (n > 0 && (!records || !path_length || !path_heading || !weighted_cost))) return fail(c, FS_E_INVALID, "null pointer");
     if (n == 0) return FS_OK;
-    FS_HIP(c, c->d_records.ensure(n)); FS_HIP(c, c->d_len.ensure(n)); FS_HIP(c, c->d_head.ensure(n));
+    const size_t nn = (size_t)n, pad = (nn + 15) & ~(size_t)15;
+    const size_t o_rec = 0, o_len = o_rec + sizeof(fs_record) * nn, o_head = o_len + 8 * nn, o_black = o_head + 8 * nn;
+    const size_t total_in = o_black + pad;
+    FS_HIP(c, c->h_in.ensure(total_in));
+    FS_HIP(c, c->d_in.ensure(total_in));
+    std::memcpy(c->h_in.p + o_rec, records, sizeof(fs_record) * nn);
+    std::memcpy(c->h_in.p + o_len, path_length, 8 * nn);
+    std::memcpy(c->h_in.p + o_head, path_heading, 8 * nn);
+    if (blacklisted) std::memcpy(c->h_in.p + o_black, blacklisted, nn);
+    FS_HIP(c, hipMemcpyAsync(c->d_in.p, c->h_in.p, blacklisted ? total_in : o_black, hipMemcpyHostToDevice, c->stream));
     FS_HIP(c, c->d_cost.ensure(n)); FS_HIP(c, c->d_au.ensure(n)); FS_HIP(c, c->d_du.ensure(n));
     FS_HIP(c, c->d_order.ensure(n)); FS_HIP(c, c->d_err.ensure(1));
-    FS_HIP(c, hipMemcpyAsync(c->d_records.p, records, sizeof(fs_record) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    FS_HIP(c, hipMemcpyAsync(c->d_len.p, path_length, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    FS_HIP(c, hipMemcpyAsync(c->d_head.p, path_heading, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    if (blacklisted) {
-        FS_HIP(c, c->d_black.ensure(n));
-        FS_HIP(c, hipMemcpyAsync(c->d_black.p, blacklisted, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    const int rc = fs_rank_candidates_dev(c, n, reinterpret_cast<const fs_record *>(c->d_in.p + o_rec),
+                                          blacklisted ? reinterpret_cast<const uint8_t *>(c->d_in.p + o_black) : nullptr,
+                                          reinterpret_cast<const double *>(c->d_in.p + o_len), reinterpret_cast<const double *>(c->d_in.p + o_head),
+                                          alpha, beta, max_vx, max_wz, c->d_cost.p, c->d_au.p, c->d_du.p, c->d_order.p, c->d_err.p);
+    if (rc) return rc;
+    struct Col { void *host; const void *dev; size_t bytes; };
+    const Col cols[5] = {{weighted_cost, c->d_cost.p, 8 * nn}, {arrival_utility, c->d_au.p, 8 * nn}, {distance_utility, c->d_du.p, 8 * nn},
+                         {order, c->d_order.p, 4 * nn}, {nullptr, c->d_err.p, 4}};
+    size_t total = 16;
+    for (const Col &col : cols) if (col.host) total += (col.bytes + 15) & ~(size_t)15;
+    FS_HIP(c, c->h_out.ensure(total));
+    FS_HIP(c, hipMemcpyAsync(c->h_out.p, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
+    size_t off = 16;
+    for (const Col &col : cols) {
+        if (!col.host) continue;
+        FS_HIP(c, hipMemcpyAsync(c->h_out.p + off, col.dev, col.bytes, hipMemcpyDeviceToHost, c->stream));
+        off += (col.bytes + 15) & ~(size_t)15;
     }
-    {
-        ScopedTimer t(c, 3);
-        FS_HIP(c, fs_launch_rank(n, c->d_records.p, blacklisted ? c->d_black.p : nullptr, c->d_len.p, c->d_head.p,
-                                 alpha, beta, max_vx, max_wz, c->max_gt, c->d_cost.p, c->d_au.p, c->d_du.p,
-                                 c->d_order.p, c->d_err.p, &c->rank_scratch, &c->rank_scratch_bytes, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    off = 16;
+    for (const Col &col : cols) {
+        if (!col.host) continue;
+        std::memcpy(col.host, c->h_out.p + off, col.bytes);
+        off += (col.bytes + 15) & ~(size_t)15;
     }
     int32_t err = 0;
-    FS_HIP(c, hipMemcpyAsync(&err, c->d_err.p, 4, hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipMemcpyAsync(weighted_cost, c->d_cost.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (arrival_utility) FS_HIP(c, hipMemcpyAsync(arrival_utility, c->d_au.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (distance_utility) FS_HIP(c, hipMemcpyAsync(distance_utility, c->d_du.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    if (order) FS_HIP(c, hipMemcpyAsync(order, c->d_order.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    FS_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(&err, c->h_out.p, 4);
     if (err) return fail(c, FS_E_RANGE, "utility outside [0,1] (the reference throws: FrontierCostsManager.cpp:148-149,173-174)");
     return FS_OK;
 }

@@ -488,9 +488,13 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // times 5/4 plus 1/32 takes over when it is smaller (only candidates with >= 16 k landmarks scanned count) — a dense slab seen from inside (REF2D) holds many landmarks per voxel
     // and was being scored in two passes for nothing.  A candidate that outgrows the prediction overflows its table, goes to
     // the HBM tier (correct, slower) and raises the ratio for the next call.
+    // The number of passes decides the order in which a candidate's fp32 terms are added: with the learnt ratio the LAST BITS of
+    // info / trace / log det depend on the calls this context has finished before (and, under fs_multi, on which member scored
+    // the candidate: each learns for itself); the integer outputs never do.  "fim.learn" 0 (FsFimArgs::learn) predicts with the
+    // fixed cap alone for runs that must reproduce those bits.
     int skip32_eff = a.skip32;
     {
-        const uint32_t seen = (uint32_t)a.counters[12];
+        const uint32_t seen = a.learn ? (uint32_t)a.counters[12] : 0u;
         if (seen != 0u) {
             const int s = (int)((seen * 5u + 31u) / 32u) + 1;
             skip32_eff = s < skip32_eff ? (s > 2 ? s : 2) : skip32_eff;

@@ -157,6 +157,7 @@ struct FsFimArgs {
     // specialised workers (fs_fim.hip): info_only — the call reads info_ref / n_voxels only (fs_score_fim with NULL for the other
     // columns: what isPoseSafe needs); yaw_only — every pose record is a rotation about Z (checked on the host)
     int32_t info_only, yaw_only;
+    int32_t learn;                    // 1: predict scoring passes with the voxel ratio learnt from finished calls (counters[12]); 0: skip32 only
     float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;

@@ -212,6 +212,7 @@ int fs_multi_score_arrival(fs_multi *m, int32_t n, const double *goal_xyz, const
                                               ray_counts ? ray_counts + per * (size_t)l : nullptr, arrival + l, argmax + l, yaw + l, achievable + l, status + l);
         if (rc != FS_OK) {
             first_error = multi_fail(m, rc, "block %d (candidates %d..%d, device %d): %s", g, l, h, m->device[(size_t)g], fs_last_error(m->ctx[(size_t)g]));
+            (void)fs_synchronize(m->ctx[(size_t)g]);     // a begin that failed half-way may have queued transfers out of this member's staging buffers: drained before anybody reuses them
             break;
         }
         ++launched;
@@ -242,6 +243,7 @@ int fs_multi_score_candidates(fs_multi *m, int32_t n, const double *goal_xyz, co
                                                  blacklisted ? blacklisted + l : nullptr, achievable_in ? achievable_in + l : nullptr);
         if (rc != FS_OK) {
             first_error = multi_fail(m, rc, "block %d (candidates %d..%d, device %d): %s", g, l, hi[(size_t)g], m->device[(size_t)g], fs_last_error(m->ctx[(size_t)g]));
+            (void)fs_synchronize(m->ctx[(size_t)g]);     // (as in fs_multi_score_arrival)
             break;
         }
         ++launched;

@@ -214,6 +214,26 @@ def make_workload(name: str, *, n_cand: int | None = None, n_landmarks: int | No
                     polygon=(origin[0], origin[1], origin[0] + n * res, origin[1] + n * res))
 
 
+def candidate_block(w: Workload, name: str, block: int, n_cand: int | None = None):
+    """Block `block` of a longer candidate list over the SAME map and cloud (weak scaling: rank r scores block r, and needs
+    nothing of the other ranks' blocks).  Block 0 is the workload's own list; the others are drawn from the same frontier cells
+    with a generator of their own, seeded by (config, block).  Returns (goals, frontier_size, blacklisted)."""
+    cfg = CONFIGS[name]
+    nc = cfg["n_cand"] if n_cand is None else n_cand
+    if block == 0 and nc == w.goals.shape[0]:
+        return w.goals, w.frontier_size, w.blacklisted
+    rng = np.random.Generator(np.random.PCG64([SEED_BASE + cfg["index"], 0xB10C, int(block)]))
+    fc = _frontier_cells(rng, w.cells, nc, reach=cfg.get("reach", 1))
+    goals = (fc + 0.5) * w.resolution + np.asarray(w.origin)[None]
+    if cfg["nz"] == 1:
+        goals[:, 2] = w.origin[2]
+    if cfg.get("jitter"):
+        goals[:, :2] += rng.uniform(-0.5, 0.5, size=(nc, 2)) * w.resolution
+    fsize = rng.integers(1, 31, size=nc).astype(np.int32)
+    black = (rng.random(nc) < 0.01).astype(np.uint8)
+    return np.ascontiguousarray(goals, dtype=np.float64), fsize, black
+
+
 def dense_to_bricks(cells: np.ndarray, default_value: int = 255):
     """Sparse wire format of fs_upload_grid_bricks (BASELINE.json configs[4]): the 8x8x8 bricks that hold anything but
     `default_value`.  Returns (brick_xyz int32 [n][3] in brick units, brick_cells uint8 [n][512], index (z*8 + y)*8 + x)."""

@@ -326,6 +326,17 @@ int fs_rank_candidates(fs_ctx *ctx, int32_t n, const fs_record *records, const u
                        double *weighted_cost, double *arrival_utility, double *distance_utility,
                        int32_t *order);
 
+/* Same, behind the scoring call on the device: every pointer is device memory (d_records = the records fs_score_candidates_dev
+ * wrote, or the receive buffer of the all-gather), launched on the context's stream and NOT waited for — score and rank run
+ * back to back without the records ever visiting the host ("fused after scoring").  d_arrival_utility,
+ * d_distance_utility, d_order may be NULL (not wanted).  d_range_error (one int32, or NULL): non-zero after the kernels have run
+ * where the reference would throw (FS_E_RANGE of the host form) — read it together with the results. */
+int fs_rank_candidates_dev(fs_ctx *ctx, int32_t n, const fs_record *d_records, const uint8_t *d_blacklisted,
+                           const double *d_path_length, const double *d_path_heading,
+                           double alpha, double beta, double max_vx, double max_wz,
+                           double *d_weighted_cost, double *d_arrival_utility, double *d_distance_utility,
+                           int32_t *d_order, int32_t *d_range_error);
+
 #ifdef __cplusplus
 }
 #endif

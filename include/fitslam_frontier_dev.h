@@ -34,7 +34,12 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * walk (identical results in every case; DESIGN.md 4.1 holds the measured table).
  * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
  * landmarks scanned, in 32nds, that decides the number of scoring passes — the cap under which the worker uses what
- * finished calls on the cloud have shown: DESIGN.md 4.2). */
+ * finished calls on the cloud have shown: DESIGN.md 4.2).
+ * "fim.learn" (default 1): 0 = predict the passes with the fixed cap alone.  The number of passes decides the order in which a
+ * candidate's float32 terms are added, so with learning on the LAST BITS of info / trace / log det depend on the calls a
+ * context has finished before (and, under fs_multi, on the member that scored the candidate); integers never do.
+ * "fim.specialise" (default 1): 0 = always the general FIM worker (no INFO_ONLY / YAW_ONLY instantiation; identical integers,
+ * float sums to the last bits) — the A/B switch of tests/test_gpu_reference_visibility.py. */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
 /* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
  * 4 = candidates scored in several voxel-partitioned passes, 5 = candidates re-scored with the table in HBM,

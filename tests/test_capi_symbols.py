@@ -105,3 +105,19 @@ def test_fim_kernels_keep_their_register_budget():
                 seen += 1
                 assert u["vgprs"] <= max_vgprs and u["scratch"] <= max_scratch, (name, u)
     assert seen >= 4
+
+
+def test_concurrent_builds_take_turns(tmp_path):
+    """N ranks of one launcher may all decide to build: the build runs under an exclusive lock and re-checks the content stamp
+    once it holds it (fit-slam_amd/_build.py), so the second process compiles nothing.  Here: two processes call build() at
+    once on an up-to-date tree and both return the library; needs_build() goes by content, not by timestamps."""
+    import subprocess
+    import sys
+    code = ("import importlib, sys, os; sys.path.insert(0, %r); b = importlib.import_module('fit-slam_amd._build'); "
+            "os.utime(os.path.join(b.CSRC, 'fs_capi.hip')); "          # a newer timestamp alone must not trigger a build
+            "assert not b.needs_build(); print(b.build())") % ROOT
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+        assert out.strip().endswith("libfitslam_frontier.so")

@@ -335,6 +335,32 @@ def test_rank_matches_oracle(fs, oracle, scorer):
     for k in ("weighted_cost", "arrival_utility", "distance_utility"):
         np.testing.assert_array_equal(got[k], want[k])
     np.testing.assert_array_equal(got["order"], np.argsort(want["weighted_cost"], kind="stable"))
+    # the device-resident form behind the scoring call: records straight from fs_score_candidates_dev, nothing visits the host
+    import torch
+    dev = torch.device("cuda", 0)
+    d_goal = torch.from_numpy(w.goals).to(dev); d_fs = torch.from_numpy(w.frontier_size).to(dev); d_bl = torch.from_numpy(w.blacklisted).to(dev)
+    d_rec = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    d_len = torch.from_numpy(plen).to(dev); d_head = torch.from_numpy(phead).to(dev)
+    d_cost = torch.zeros(n, dtype=torch.float64, device=dev); d_au = torch.zeros_like(d_cost); d_du = torch.zeros_like(d_cost)
+    d_order = torch.zeros(n, dtype=torch.int32, device=dev); d_err = torch.ones(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    scorer.score_candidates_dev(n, d_goal.data_ptr(), d_fs.data_ptr(), d_bl.data_ptr(), 0, d_rec.data_ptr())
+    scorer.rank_candidates_dev(n, d_rec.data_ptr(), d_len.data_ptr(), d_head.data_ptr(), d_cost.data_ptr(), d_au.data_ptr(),
+                               d_du.data_ptr(), d_order.data_ptr(), d_black=d_bl.data_ptr(), d_err=d_err.data_ptr())
+    scorer.synchronize()
+    assert int(d_err.cpu()[0]) == 0
+    np.testing.assert_array_equal(d_cost.cpu().numpy(), want["weighted_cost"])
+    np.testing.assert_array_equal(d_au.cpu().numpy(), want["arrival_utility"])
+    np.testing.assert_array_equal(d_du.cpu().numpy(), want["distance_utility"])
+    np.testing.assert_array_equal(d_order.cpu().numpy(), got["order"])
+    # optional columns left out; a utility outside [0, 1] raises the flag instead of throwing (FrontierCostsManager.cpp:148-149)
+    scorer.set_arrival_limits(1.0, 0.1)                               # arrival / max_gt > 1
+    scorer.rank_candidates_dev(n, d_rec.data_ptr(), d_len.data_ptr(), d_head.data_ptr(), d_cost.data_ptr(), d_err=d_err.data_ptr())
+    scorer.synchronize()
+    assert int(d_err.cpu()[0]) != 0
+    with pytest.raises(fs.capi.FsError):
+        scorer.rank_candidates(rec, plen, phead, blacklisted=w.blacklisted)
+    scorer.set_arrival_limits(400.0, 40.0)
 
 
 def test_fim_culling_is_exact(fs, oracle, scorer, ref_table):

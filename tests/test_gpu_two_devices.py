@@ -1,0 +1,80 @@
+"""What only a box with two (or more) physical GPUs can show — skipped on the one-GPU leases this build is developed on, the
+first real evidence on the driver's multi-GPU node:
+
+  * fs_multi_create({0, 1}): the records of a list scored half on each device equal a single context's (north_star's partition,
+    the reference's in-process call shape: DEP/src/ExplorationBT.cpp:376-410);
+  * bench.py --gpus 2 --scaling strong through its own launcher: two ranks over RCCL, one all-gather per step, n_gpus == 2 in
+    the line, the gathered list gated against the oracle in every rank's block, both ranks named in the log.
+
+torch.cuda.device_count() does not initialise the GPU on this image, so collecting this module is harmless anywhere."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_devices():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+two_gpus = pytest.mark.skipif(_n_devices() < 2, reason="needs two physical GPUs")
+
+
+@two_gpus
+def test_fs_multi_on_two_physical_devices_equals_a_single_context(fs):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("multi_device_helpers", os.path.join(ROOT, "tests", "test_multi_device.py"))
+    helpers = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(helpers)
+    _same_records, _stage = helpers._same_records, helpers._stage
+    w = fs.synth.make_workload("C2")
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+              robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+    one = fs.FrontierScorer(device=0)
+    mx1 = _stage(one, w, kw)
+    want = one.score_candidates(w.goals, w.frontier_size, w.blacklisted)
+    want_arr = one.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+    one.close()
+    m = fs.MultiScorer(devices=(0, 1))
+    assert _stage(m, w, kw) == mx1
+    for _ in range(2):
+        _same_records(m.score_candidates(w.goals, w.frontier_size, w.blacklisted), want)
+    got_arr = m.score_arrival(w.goals, w.frontier_size, w.blacklisted, n_rays_total=int(want_arr["ray_counts"][0].size))
+    for k in ("arrival", "argmax", "status", "achievable", "yaw"):
+        np.testing.assert_array_equal(got_arr[k], want_arr[k], err_msg=k)
+    np.testing.assert_array_equal(got_arr["ray_counts"].reshape(want_arr["ray_counts"].shape), want_arr["ray_counts"])
+    # the second device really worked: its context counted landmark tests of its own
+    import ctypes as C
+    L = fs.load_library()
+    v = C.c_int64()
+    assert L.fs_get_counter(L.fs_multi_ctx(m._h, 1), 11, C.byref(v), 0) == 0 and v.value > 0
+    m.close()
+
+
+@two_gpus
+def test_bench_two_ranks_over_rccl():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--steps", "3",
+                        "--warmup", "2", "--repeats", "3"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["parity"]["ok"], j["parity"]
+    assert "rank 0/2" in r.stderr and "rank 1/2" in r.stderr
+    mg = j["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step"]) == 2 and mg["all_gather_ms"] > 0 and mg["barrier_skew_ms"] >= 0
+    assert j["ranked_step"]["order_is_a_permutation"] and j["ranked_step"]["costs_ascending"] and j["ranked_step"]["range_error"] == 0
