@@ -107,6 +107,11 @@ struct fs_ctx {
     bool yaw_exact = false;        // every rotation of d_yawR is about Z with exact zeros / one (what YAW_ONLY relies on)
     int opt_bits1 = 14;            // development knobs (fs_set_option "fim.bits1", "fim.skip32")
     int opt_skip32 = 13;
+    // "fim.headroom": what the pass prediction multiplies the learnt voxel ratio by, in 32nds.  The ratio is the LARGEST any big
+    // pose showed and a pass is sized for a table 3/4 full, so 28/32 still leaves the worst pose seen at 86 % load; round 3's
+    // 5/4 sent 7 312 of C3's 20 000 poses into a second pass at the reference's visibility request where 2 943 hold more voxels
+    // than one pass takes (tools/ref_visibility_probe.py, profiles/r04/ref_visibility_pass_margin.jsonl: 1.87 -> 1.69 ms)
+    int opt_headroom = 28;
     DevBuf<unsigned long long> d_counters;
 
     // lookup table
@@ -547,6 +552,7 @@ int fill_fim_args(fs_ctx *c, FsFimArgs &a)
     a.learn = c->opt_learn ? 1 : 0;
     a.hash_bits = bits;
     a.skip32 = c->opt_skip32;
+    a.headroom = c->opt_headroom;
     a.gtable = c->d_gtable.p;
     a.ghash_bits = c->ghash_bits;
     a.counters = c->d_counters.p;
@@ -1244,6 +1250,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 2) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
+    if (std::strcmp(key, "fim.headroom") == 0 && value >= 8 && value <= 64) { c->opt_headroom = (int)value; return FS_OK; }
     return fail(c, FS_E_INVALID, "unknown option %s", key);
 }
 

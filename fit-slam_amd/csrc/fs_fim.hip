@@ -496,7 +496,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     {
         const uint32_t seen = a.learn ? (uint32_t)a.counters[12] : 0u;
         if (seen != 0u) {
-            const int s = (int)((seen * 5u + 31u) / 32u) + 1;
+            const int s = (int)((seen * (uint32_t)a.headroom + 255u) / 256u) + 1;      // headroom / 32 (5/4 by default) of the ratio, + 1/32
             skip32_eff = s < skip32_eff ? (s > 2 ? s : 2) : skip32_eff;
         }
         skip32_eff = __builtin_amdgcn_readfirstlane(skip32_eff);

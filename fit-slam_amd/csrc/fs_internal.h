@@ -188,6 +188,7 @@ struct FsFimArgs {
     // hash tables
     int32_t hash_bits;         // LDS tier (512-thread workgroups)
     int32_t skip32;            // pass-count prediction: distinct voxels <= skip32/32 of the landmarks scanned
+    int32_t headroom;          // ... and, once a ratio has been learnt, headroom/32 of it (40 = 5/4) + 1/32 when that is smaller
     uint32_t *gtable;          // tier 3: HBM tables [pool][1 << ghash_bits]
     int32_t ghash_bits;
 };

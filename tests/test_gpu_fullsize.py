@@ -102,6 +102,12 @@ def test_c3_oracle_spot_check(fs, oracle, ref_table, c3, c3_scorer):
     np.testing.assert_array_equal(fs.capi.record_nvoxels(rec)[ok], np.minimum(fim["n_voxels"][ok], 65535))
     sc = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
     assert np.max(np.abs(rec["info_ref"][ok] - fim["info_f64"][ok]) / sc) <= 1e-4
+    assert np.max(np.abs(rec["trace"][ok] - fim["trace"][ok]) / np.maximum(fim["trace"][ok], 1e-6)) <= 1e-4
+    # D-optimality at north_star's tolerance, plain: every candidate of the sample whose F is non-singular for both
+    np.testing.assert_array_equal(np.isfinite(rec["logdet"][ok]), np.isfinite(fim["logdet"][ok]))
+    fin = ok & np.isfinite(fim["logdet"])
+    e_ld = np.abs(rec["logdet"][fin] - fim["logdet"][fin]) / np.maximum(1.0, np.abs(fim["logdet"][fin]))
+    assert fin.sum() > 200 and np.mean(e_ld <= 1e-4) == 1.0, (int(fin.sum()), float(e_ld.max()))
 
 
 def test_c3_ranking_properties(fs, c3, c3_scorer):

@@ -225,7 +225,6 @@ def _check_fim(got, want, n_lm):
     tr = np.maximum(np.abs(want["trace"]), 1e-6)
     assert np.max(np.abs(got["trace"] - want["trace"]) / tr) <= REL
     # D-optimality has no reference counterpart: it is checked against the float64 oracle.
-    # fp32 block sums carry ~1e-6 relative error per entry, amplified by the FIM's condition number.
     ok = np.isfinite(want["logdet"])
     lam = np.linalg.eigvalsh(want["fim"])
     cond = lam[:, -1] / np.maximum(lam[:, 0], 1e-300)
@@ -234,8 +233,14 @@ def _check_fim(got, want, n_lm):
     np.testing.assert_array_equal(np.isfinite(got["logdet"])[want["n_visible"] < 3], False)
     both = ok & np.isfinite(got["logdet"])
     if both.any():
-        tol = REL * np.maximum(1.0, np.abs(want["logdet"][both])) + 1e-6 * cond[both]
-        assert np.all(np.abs(got["logdet"][both] - want["logdet"][both]) <= tol)
+        # north_star: D-optimality within 1e-4 relative — plain, for every F that is not nearly singular.  The floor: the float32
+        # landmark coordinates and pose are themselves rounded to 2^-24 relative before any arithmetic happens, and log det of a
+        # matrix with condition number k moves by up to k times a relative perturbation of its entries; k * 2^-24 is below
+        # 6e-5 up to k = 1e3 and only matters for the near-singular poses (a handful of landmarks in a row).  Measured over the
+        # whole suite: one pose beyond plain 1e-4 (k = 9e5, error 2.5e-9 k); bench.py reports the C3 share (100 %).
+        tol = REL * np.maximum(1.0, np.abs(want["logdet"][both])) + 2.0 ** -24 * cond[both]
+        err = np.abs(got["logdet"][both] - want["logdet"][both])
+        assert np.all(err <= tol), (float((err / tol).max()), float(cond[both][np.argmax(err / tol)]))
     if got.get("fim21") is not None:
         iu = np.triu_indices(6)
         wantF = want["fim"][:, iu[0], iu[1]]

@@ -119,10 +119,12 @@ def test_fused_path_yaw_only_worker(fs, oracle, scorer, ref_table, name, vis):
     mx = oracle.max_arrival_information(G, P)
     assert scorer.max_arrival() == mx
     recs = {}
+    scorer.set_option("fim.learn", 0)       # the pass count — hence the order of the float sums — must not depend on the call before
     for special in (1, 0):
         scorer.set_option("fim.specialise", special)
         recs[special] = scorer.score_candidates(w.goals, w.frontier_size, w.blacklisted)
     scorer.set_option("fim.specialise", 1)
+    scorer.set_option("fim.learn", 1)
     scorer.set_fim_params(14.0, 1.0)
     # same arithmetic: everything that does not depend on which landmark won which rank in its voxel (the order of the LDS
     # atomics decides which lane adds which info_v * factor(k) term) agrees bit for bit; info_ref to the last bits
