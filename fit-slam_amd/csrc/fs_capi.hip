@@ -770,7 +770,8 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
     FS_HIP(c, hipSetDevice(c->device));
     if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
-    if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
+    // (cell offsets are 32-bit unsigned in the walks, one z step is a signed 32-bit stride; everything else indexes in 64 bits)
+    if (total >= (1ull << 32) || (uint64_t)nx * (uint64_t)ny >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^32 cells (and 2^31 per z slice)");
     FS_HIP(c, c->d_cells.ensure((size_t)total));
     FS_HIP(c, hipMemcpyAsync(c->d_cells.p, cells, (size_t)total, hipMemcpyHostToDevice, c->stream));
     {
@@ -794,7 +795,8 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
     if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
     if ((nx & 7) || (ny & 7) || (nz & 7)) return fail(c, FS_E_INVALID, "brick upload needs dimensions that are multiples of 8");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
-    if (total >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^31 cells");
+    // (cell offsets are 32-bit unsigned in the walks, one z step is a signed 32-bit stride; everything else indexes in 64 bits)
+    if (total >= (1ull << 32) || (uint64_t)nx * (uint64_t)ny >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^32 cells (and 2^31 per z slice)");
     FS_HIP(c, c->d_cells.ensure((size_t)total));
     FS_HIP(c, hipMemsetAsync(c->d_cells.p, default_value, (size_t)total, c->stream));
     if (n_bricks > 0) {

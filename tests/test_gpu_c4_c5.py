@@ -129,7 +129,53 @@ def test_brick_upload_rejects_what_it_cannot_stage(fs):
             s.upload_grid_bricks((12, 16, 16), (0, 0, 0), 0.05, np.zeros((0, 3), np.int32), np.zeros((0, 512), np.uint8))
         with pytest.raises(fs.FsError):                       # a brick outside the grid
             s.upload_grid_bricks((16, 16, 16), (0, 0, 0), 0.05, np.array([[2, 0, 0]], np.int32), np.zeros((1, 512), np.uint8))
-        with pytest.raises(fs.FsError):                       # dense staging is limited to 2^31 cells (documented hard limit)
-            s.upload_grid_bricks((2048, 1024, 1024), (0, 0, 0), 0.05, np.zeros((0, 3), np.int32), np.zeros((0, 512), np.uint8))
+        with pytest.raises(fs.FsError):                       # dense staging is limited to 2^32 cells (documented hard limit)
+            s.upload_grid_bricks((2048, 2048, 1024), (0, 0, 0), 0.05, np.zeros((0, 3), np.int32), np.zeros((0, 512), np.uint8))
+    finally:
+        s.close()
+
+
+def test_grid_beyond_2_31_cells_walks_like_the_same_cells_in_a_small_grid(fs):
+    """A 1024 x 1024 x 2560 grid (2.7 G cells; cell offsets past 2^31 — a shape whose brick strides still fit the class walk's 24-bit multiplies) that is unknown everywhere except for C1's 64^3 cells in its
+    far corner: fans inside that corner, clamped to it by the polygon, must return exactly what the same cells return as a grid of
+    their own (translation invariance; resolution 1/16 m so that every world <-> cell conversion is exact in both frames).  Both
+    walks: the byte image (32-bit unsigned offsets up to 2^32) and the class image (brick addresses)."""
+    w = fs.synth.make_workload("C1")
+    res = 0.0625
+    n = 64
+    sub = np.ascontiguousarray(w.cells)                                 # [64][64][64]
+    NX, NY, NZ = 1024, 1024, 2560
+    x0, y0, z0 = NX - n - 8, NY - n - 16, NZ - n - 8                   # far corner: offsets > 2^31 (z0 * NX * NY = 2.6e9)
+    big_origin = (-8.0, -8.0, -64.0)
+    small_origin = (big_origin[0] + x0 * res, big_origin[1] + y0 * res, big_origin[2] + z0 * res)
+    cell = ((w.goals - np.asarray(w.origin)) / w.resolution - 0.5).round().astype(np.int64)          # C1's goal cells
+    goals = (cell + 0.5) * res + np.asarray(small_origin)
+    poly = (small_origin[0], small_origin[1], small_origin[0] + (n - 1 + 0.5) * res, small_origin[1] + (n - 1 + 0.5) * res)
+    kw = dict(max_camera_depth=40 * res, delta_theta=w.delta_theta, camera_fov=w.camera_fov, robot_radius=0.6 * res / 0.05,
+              n_rays=w.n_yaw, elev=(0.0,), polygon=poly)
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.set_ray_params(**kw)
+        s.upload_grid(sub, small_origin, res)
+        s.set_arrival_limits(400.0, 40.0)
+        want = {lay: None for lay in (1, 2)}
+        for lay in (1, 2):
+            s.set_option("ray.layout", lay)
+            want[lay] = s.score_arrival(goals, w.frontier_size, w.blacklisted)
+        big = np.full((NZ, NY, NX), 255, dtype=np.uint8)
+        big[z0:z0 + n, y0:y0 + n, x0:x0 + n] = sub
+        # the footprint disc may look past the corner block in the big grid: keep what it would see there equal to "off the map"
+        # (never lethal) — unknown cells are not 254
+        s.upload_grid(big, big_origin, res)
+        del big
+        s.set_arrival_limits(400.0, 40.0)
+        assert (want[1]["arrival"] > 0).sum() > 50
+        for lay in (1, 2):
+            s.set_option("ray.layout", lay)
+            got = s.score_arrival(goals, w.frontier_size, w.blacklisted)
+            for k in ("status", "arrival", "argmax", "achievable", "ray_counts"):
+                np.testing.assert_array_equal(got[k], want[lay][k], err_msg=f"layout {lay}: {k}")
+            np.testing.assert_array_equal(got["yaw"], want[lay]["yaw"])
+        np.testing.assert_array_equal(want[1]["ray_counts"], want[2]["ray_counts"])
     finally:
         s.close()
