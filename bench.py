@@ -265,6 +265,9 @@ def run_latency(args) -> int:
         kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
                   robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
         sc = fs.FrontierScorer(device=0)
+        for kv in args.option:
+            k, v = kv.split("=", 1)
+            sc.set_option(k, float(v))
         sc.set_ray_params(**kw); sc.upload_grid(w.cells, w.origin, w.resolution); sc.upload_landmarks(w.landmarks)
         sc.lookup_generate(); sc.set_fim_params(14.0, args.fim_angle)
         mx = sc.max_arrival()

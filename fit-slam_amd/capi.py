@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim", "fs_information_frontier_pair",
     "fs_upload_keyframes", "fs_information_for_pose",
-    "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_rank_candidates_dev", "fs_selftest_fp64",
+    "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_rank_candidates_dev", "fs_get_frontier_costs", "fs_selftest_fp64",
     "fs_multi_create", "fs_multi_destroy", "fs_multi_num_devices", "fs_multi_ctx", "fs_multi_last_error", "fs_multi_shard_bounds",
     "fs_multi_set_option", "fs_multi_set_ray_params", "fs_multi_upload_grid", "fs_multi_upload_landmarks", "fs_multi_lookup_generate",
     "fs_multi_lookup_load", "fs_multi_set_fim_params", "fs_multi_max_arrival", "fs_multi_score_arrival", "fs_multi_score_candidates",
@@ -123,6 +123,7 @@ def load_library(build: bool = True):
     L.fs_score_candidates_dev.argtypes = [vp, i32] + [vp] * 5
     L.fs_rank_candidates.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp]
     L.fs_rank_candidates_dev.argtypes = [vp, i32, vp, vp, vp, vp, dbl, dbl, dbl, dbl, vp, vp, vp, vp, vp]
+    L.fs_get_frontier_costs.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, dbl, dbl, dbl, dbl, C.c_int, vp, vp, vp, vp, vp]
     L.fs_selftest_fp64.argtypes = [vp, i32, C.POINTER(i64)]
     L.fs_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
     L.fs_multi_destroy.argtypes = [vp]
@@ -394,6 +395,22 @@ class FrontierScorer:
         self._check(self._L.fs_rank_candidates(self._h, n, _p(rec), _p(bl), _p(pl), _p(ph), alpha, beta, max_vx, max_wz,
                                                _p(cost), _p(au), _p(du), _p(order)))
         return dict(weighted_cost=cost, arrival_utility=au, distance_utility=du, order=order)
+
+    def get_frontier_costs(self, goal_xyz, path_length, path_heading, frontier_size=None, blacklisted=None, achievable_in=None,
+                           with_fim=False, alpha=0.25, beta=1.0, max_vx=0.5, max_wz=0.5):
+        """CostAssigner::getFrontierCosts as one call: arrival information (+ Fisher information) + U1 costs + order."""
+        goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+        n = goal.shape[0]
+        pl = np.ascontiguousarray(path_length, dtype=np.float64)
+        ph = np.ascontiguousarray(path_heading, dtype=np.float64)
+        fs = None if frontier_size is None else np.ascontiguousarray(frontier_size, dtype=np.int32)
+        bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+        ai = None if achievable_in is None else np.ascontiguousarray(achievable_in, dtype=np.uint8)
+        rec = np.zeros(n, dtype=RECORD_DTYPE)
+        cost = np.zeros(n); au = np.zeros(n); du = np.zeros(n); order = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_get_frontier_costs(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(pl), _p(ph), alpha, beta, max_vx, max_wz,
+                                                  1 if with_fim else 0, _p(rec), _p(cost), _p(au), _p(du), _p(order)))
+        return dict(records=rec, weighted_cost=cost, arrival_utility=au, distance_utility=du, order=order)
 
     def rank_candidates_dev(self, n, d_records, d_path_length, d_path_heading, d_cost, d_au=0, d_du=0, d_order=0, d_black=0,
                             d_err=0, alpha=0.25, beta=1.0, max_vx=0.5, max_wz=0.5):

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -19,6 +20,10 @@ hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *
                           double max_vx, double max_wz, double max_gt, double *d_cost, double *d_au,
                           double *d_du, int32_t *d_order, int32_t *d_err, void **scratch, size_t *scratch_bytes,
                           hipStream_t s);
+
+// Counts every (re)allocation of device / page-locked memory the library makes, in any context: a captured launch graph holds
+// raw pointers, and is only replayed while this number is what it was at capture time.
+uint64_t fs_alloc_generation = 0;
 
 namespace {
 
@@ -32,6 +37,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
         size_t want = std::max<size_t>(n, 64);
+        ++fs_alloc_generation;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
         if (e == hipSuccess) cap = want;
         return e;
@@ -55,6 +61,7 @@ struct PinnedBuf {
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
         const size_t want = std::max<size_t>(bytes, 4096);
+        ++fs_alloc_generation;
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault);
         if (e == hipSuccess) cap = want;
         return e;
@@ -69,6 +76,15 @@ struct PinnedBuf {
 struct TimedLaunch {
     int kind;
     hipEvent_t start, stop;
+};
+
+// One captured launch sequence of a small host-buffer call: valid while the context's epoch (every staging /
+// parameter call bumps it) and the allocation generation are what they were when it was captured.
+struct GraphEntry {
+    hipGraphExec_t exec = nullptr;
+    uint64_t stamp = 0;          // epoch + allocation generation the graph was captured under
+    uint64_t warm_stamp = 0;     // ... a plain call has run under (it made every allocation the sequence needs)
+    bool broken = false;         // capture failed once: this sequence stays on plain launches
 };
 
 }  // namespace
@@ -182,6 +198,12 @@ struct fs_ctx {
     uint32_t *sort_costmap = nullptr;
     int opt_layout = 0;            // "ray.layout": 0 by ray length, 1 row-major byte walk, 2 class-image walk
 
+    // launch graphs of the small host-buffer calls ("graph" option; off while kernel timing is on)
+    bool opt_graph = false;        // measured 5-7 us SLOWER per call than plain launches on ROCm 7.2 (profiles/r04/small_call_graphs.json): off by default
+    uint64_t epoch = 1;
+    std::map<uint64_t, GraphEntry> graphs;
+    DevBuf<char> d_out;            // packed results of fs_get_frontier_costs (records | cost | utilities | order | error flag)
+
     // timing
     bool timing = false;
     std::vector<TimedLaunch> launches;
@@ -208,6 +230,66 @@ int fail(fs_ctx *c, int code, const char *fmt, ...)
         hipError_t e__ = (call);                                                                 \
         if (e__ != hipSuccess) return fail((c), FS_E_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
+
+// ---------------------------------------------------------------- launch graphs for the small host-buffer calls
+// The reference scores tens of frontiers per behaviour-tree tick and ONE pose per isPoseSafe: such a call is a dozen launches of
+// nearly empty kernels, and what it costs is launch latency.  `enqueue` puts the call's whole device-side sequence — one
+// transfer in, the kernels, one transfer out; fixed sizes, fixed pointers, no allocation, no synchronisation — on the context's
+// stream.  The first call in a given state runs it plainly (and makes every allocation it needs), the second captures it into a
+// hipGraph, every later one replays the graph with ONE launch.  Any staging or parameter call (epoch) and any reallocation
+// (fs_alloc_generation) sends the sequence through that cycle again; a capture that fails leaves it on plain launches.
+// MEASURED (profiles/r04/small_call_graphs.json, alternating runs in one session): the replay costs 5-7 us MORE per call than the
+// six plain launches it replaces (REF2D, one frontier: 61.0 -> 66.7 us; 50 frontiers: 86.5 -> 92.5 us) — hipGraphLaunch is the
+// expensive launch on this runtime.  The "graph" option is therefore OFF by default; the path stays, tested, for runtimes
+// where that changes.
+#define FS_GRAPH_MAX_N 1024      // candidates per graphed call: buckets of 2^k up to here (below the spatial sort's threshold)
+
+template <typename F>
+int run_maybe_graphed(fs_ctx *c, uint64_t key, F enqueue)
+{
+    if (!c->opt_graph || c->timing) return enqueue();
+    if (c->graphs.size() > 256) {                              // (a caller that varies the parameters baked into a key without end)
+        for (auto &g : c->graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+        c->graphs.clear();
+    }
+    GraphEntry &g = c->graphs[key];
+    const uint64_t stamp = (c->epoch << 32) ^ fs_alloc_generation;
+    if (g.broken) return enqueue();
+    if (g.exec && g.stamp == stamp) {
+        if (hipGraphLaunch(g.exec, c->stream) == hipSuccess) return FS_OK;
+        g.broken = true;
+        return enqueue();
+    }
+    if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+    if (g.warm_stamp != stamp) {
+        const int rc = enqueue();                              // plain: allocations, lazily cut images, attribute calls happen here
+        g.warm_stamp = (c->epoch << 32) ^ fs_alloc_generation;
+        return rc;
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) != hipSuccess) { g.broken = true; return enqueue(); }
+    const int rc = enqueue();
+    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+    const bool same_state = ((c->epoch << 32) ^ fs_alloc_generation) == stamp;
+    if (rc != FS_OK || e_end != hipSuccess || !graph || !same_state ||
+        hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        g.exec = nullptr; g.broken = true;
+        (void)hipGetLastError();
+        return rc != FS_OK ? rc : enqueue();                   // nothing has run yet: the capture only recorded
+    }
+    (void)hipGraphDestroy(graph);
+    g.stamp = stamp;
+    if (hipGraphLaunch(g.exec, c->stream) != hipSuccess) { g.broken = true; return enqueue(); }
+    return FS_OK;
+}
+
+int graph_bucket(int32_t n)
+{
+    int b = 1;
+    while (b < n) b <<= 1;
+    return b;
+}
 
 double std_min(double a, double b) { return (b < a) ? b : a; }
 double std_max(double a, double b) { return (a < b) ? b : a; }
@@ -398,6 +480,7 @@ int build_dense(fs_ctx *c)
     }
     FS_HIP(c, hipStreamSynchronize(c->stream));
     c->have_table = true;
+    ++c->epoch;
     return FS_OK;
 }
 
@@ -477,6 +560,7 @@ int fill_ray_args(fs_ctx *c, FsRayArgs &a, bool class_ok = true)
                 return fail(c, FS_E_HIP, "could not stage the class image of the grid");
             std::memcpy(c->cls_ranges, want, sizeof want);
             c->have_cls = true;
+            ++c->epoch;
         }
         a.grid = grid_dev(c);
         a.layout = 1;
@@ -622,6 +706,8 @@ void fs_ctx_destroy(fs_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &t : c->launches) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto &g : c->graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+    c->d_out.release();
     c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_cls.release();
     c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
@@ -750,6 +836,7 @@ int fs_set_ray_params(fs_ctx *c, const fs_ray_params *p)
     c->n_yaw = n_yaw; c->n_elev = p->n_elev; c->window = k;
     c->yaw_exact = yaw_exact;
     c->have_ray = true;
+    ++c->epoch;
     c->max_gt = 0.0; c->min_gt = 0.0;
     return FS_OK;
 }
@@ -784,6 +871,7 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
     c->res = resolution;
     c->have_grid = true;
     c->max_gt = 0.0; c->min_gt = 0.0;
+    ++c->epoch;
     return FS_OK;
 }
 
@@ -823,6 +911,7 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
     c->res = resolution;
     c->have_grid = true;
     c->max_gt = 0.0; c->min_gt = 0.0;
+    ++c->epoch;
     return FS_OK;
 }
 
@@ -922,6 +1011,7 @@ int fs_set_arrival_limits(fs_ctx *c, double max_gt, double min_gt)
 {
     if (!c) return FS_E_INVALID;
     c->max_gt = max_gt; c->min_gt = min_gt;
+    ++c->epoch;
     return FS_OK;
 }
 
@@ -964,6 +1054,7 @@ int fs_max_arrival(fs_ctx *c, double *max_value, double *max_gt, double *min_gt)
     }
     c->max_gt = arrival * c->rp.factor_max;           // :186
     c->min_gt = c->rp.factor_min * c->max_gt;         // :188
+    ++c->epoch;
     if (max_value) *max_value = (double)arrival;
     if (max_gt) *max_gt = c->max_gt;
     if (min_gt) *min_gt = c->min_gt;
@@ -1225,6 +1316,7 @@ int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st)
     c->ghash_bits = gb;
     FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
     c->have_lm = true;
+    ++c->epoch;
     return FS_OK;
 }
 
@@ -1243,6 +1335,8 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
 int fs_set_option(fs_ctx *c, const char *key, double value)
 {
     if (!c || !key) return FS_E_INVALID;
+    ++c->epoch;                                            // (whatever the knob is, captured launch sequences are taken again)
+    if (std::strcmp(key, "graph") == 0) { c->opt_graph = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.specialise") == 0) { c->opt_special = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.learn") == 0) { c->opt_learn = value != 0.0; return FS_OK; }
@@ -1352,6 +1446,7 @@ int fs_set_fim_params(fs_ctx *c, const fs_fim_params *p)
     if (!(p->max_dist > 0.0) || !(p->max_angle > 0.0)) return fail(c, FS_E_INVALID, "max_dist and max_angle must be positive");
     if (p->max_dist != c->fp.max_dist || p->max_angle != c->fp.max_angle) reset_voxel_ratio(c);
     c->fp = *p;
+    ++c->epoch;
     return FS_OK;
 }
 
@@ -1409,7 +1504,6 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
     float *Rt = reinterpret_cast<float *>(c->h_in.p);
     for (int32_t i = 0; i < n; ++i) pose_to_rt(pose7 + 7 * (size_t)i, Rt + 12 * (size_t)i);
     FS_HIP(c, c->d_Rt.ensure(nn * 12));
-    FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, Rt, nn * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     rc = ensure_candidate_scratch(c, n, fim21 != nullptr);
     if (rc) return rc;
     FsFimArgs a{};
@@ -1430,20 +1524,30 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
     // scanned than the 13/32 the general worker caps its pass prediction at — C3, cone off: up to 0.5; an extra pass costs a
     // re-test of the landmarks, an overflow the HBM tier)
     if (a.info_only && a.skip32 < 20) a.skip32 = 20;
-    rc = run_fim(c, a);
-    if (rc) return rc;
     struct Col { void *host; const void *dev; size_t bytes; };
     const Col cols[6] = {{info_ref, c->d_info.p, 4 * nn}, {fim21, c->d_fim21.p, 84 * nn}, {trace, c->d_trace.p, 4 * nn},
                          {logdet, c->d_logdet.p, 4 * nn}, {n_visible, c->d_nvis.p, 4 * nn}, {n_voxels, c->d_nvox.p, 4 * nn}};
     size_t total = 0;
-    for (const Col &col : cols) if (col.host) total += (col.bytes + 15) & ~(size_t)15;
+    uint64_t col_mask = 0;
+    for (int k = 0; k < 6; ++k) if (cols[k].host) { total += (cols[k].bytes + 15) & ~(size_t)15; col_mask |= 1ull << k; }
     FS_HIP(c, c->h_out.ensure(total));
+    auto enqueue = [&]() -> int {
+        FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, c->h_in.p, nn * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        const int r = run_fim(c, a);
+        if (r) return r;
+        size_t o = 0;
+        for (const Col &col : cols) {
+            if (!col.host) continue;
+            FS_HIP(c, hipMemcpyAsync(c->h_out.p + o, col.dev, col.bytes, hipMemcpyDeviceToHost, c->stream));
+            o += (col.bytes + 15) & ~(size_t)15;
+        }
+        return FS_OK;
+    };
+    // ONE pose is isPoseSafe's call: its launch sequence is captured (per number of poses up to 4, requested columns, cull mode)
+    if (n <= 4) rc = run_maybe_graphed(c, (2ull << 40) | ((uint64_t)n << 8) | (col_mask << 1) | (uint64_t)(a.cull ? 1 : 0), enqueue);
+    else rc = enqueue();
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     size_t off = 0;
-    for (const Col &col : cols) {
-        if (!col.host) continue;
-        FS_HIP(c, hipMemcpyAsync(c->h_out.p + off, col.dev, col.bytes, hipMemcpyDeviceToHost, c->stream));
-        off += (col.bytes + 15) & ~(size_t)15;
-    }
     FS_HIP(c, hipStreamSynchronize(c->stream));
     off = 0;
     for (const Col &col : cols) {
@@ -1669,14 +1773,146 @@ int fs_score_candidates_end(fs_ctx *c, int32_t n, fs_record *records)
     return FS_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// arrival information only, device columns in, arrival-only records out (the Fisher columns of a record stay zero)
+int arrival_records_dev(fs_ctx *c, int32_t n, const double *d_goal, const int32_t *d_fsize, const uint8_t *d_black, const uint8_t *d_achin,
+                        fs_record *d_records)
+{
+    int rc = check_scoring_state(c, true, false);
+    if (rc) return rc;
+    rc = ensure_candidate_scratch(c, n, false);
+    if (rc) return rc;
+    FsRayArgs a{};
+    if (const int rc_args = fill_ray_args(c, a)) return rc_args;
+    a.n = n; a.goal = d_goal; a.frontier_size = d_fsize; a.blacklisted = d_black; a.achievable_in = d_achin;
+    a.arrival = c->d_arrival.p; a.argmax = c->d_argmax.p; a.status = c->d_status.p; a.yaw = c->d_yaw.p; a.achievable = c->d_ach.p;
+    a.records = d_records;
+    rc = maybe_sort(c, a);
+    if (rc) return rc;
+    ScopedTimer t(c, 0);
+    FS_HIP(c, fs_launch_raymarch(a, c->stream));
+    return FS_OK;
+}
+
+// The whole of a host-buffer scoring call — candidate columns (and, for ranking, the planner's path columns) in, records (and
+// costs, utilities, order) out — as ONE transfer in, the kernels, ONE transfer out and one synchronisation; up to FS_GRAPH_MAX_N
+// candidates the device-side sequence is a captured launch graph per power-of-two bucket (run_maybe_graphed): the list is
+// padded to the bucket with blacklisted dummies, which no kernel spends work on and which a stable ascending sort leaves behind
+// every real candidate.
+int frontier_costs_core(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size, const uint8_t *blacklisted,
+                        const uint8_t *achievable_in, const double *path_length, const double *path_heading,
+                        double alpha, double beta, double max_vx, double max_wz, bool with_fim,
+                        fs_record *records, double *weighted_cost, double *arrival_utility, double *distance_utility, int32_t *order)
+{
+    FS_HIP(c, hipSetDevice(c->device));
+    int rc = check_scoring_state(c, true, with_fim);
+    if (rc) return rc;
+    const bool rank = path_length != nullptr;
+    const bool graphed = c->opt_graph && !c->timing && n <= FS_GRAPH_MAX_N;
+    const int32_t cap = graphed ? graph_bucket(n) : n;
+    const size_t nn = (size_t)n, cc = (size_t)cap, pad = (cc + 15) & ~(size_t)15;
+    // input block: goal | path length | path heading | frontier size | blacklist | achievable
+    const size_t i_goal = 0, i_len = i_goal + 24 * cc, i_head = i_len + (rank ? 8 * cc : 0), i_fsize = i_head + (rank ? 8 * cc : 0);
+    const size_t i_black = (i_fsize + 4 * cc + 15) & ~(size_t)15, i_achin = i_black + pad, total_in = i_achin + pad;
+    // output block: records | cost | arrival utility | distance utility | order | range-error flag
+    const size_t o_rec = 0, o_cost = o_rec + sizeof(fs_record) * cc, o_au = o_cost + (rank ? 8 * cc : 0), o_du = o_au + (rank ? 8 * cc : 0);
+    const size_t o_order = o_du + (rank ? 8 * cc : 0), o_err = (o_order + (rank ? 4 * cc : 0) + 15) & ~(size_t)15, total_out = o_err + 16;
+    FS_HIP(c, c->h_in.ensure(total_in)); FS_HIP(c, c->d_in.ensure(total_in));
+    FS_HIP(c, c->h_out.ensure(total_out)); FS_HIP(c, c->d_out.ensure(total_out));
+    char *h = c->h_in.p;
+    std::memcpy(h + i_goal, goal_xyz, 24 * nn);
+    if (rank) { std::memcpy(h + i_len, path_length, 8 * nn); std::memcpy(h + i_head, path_heading, 8 * nn); }
+    if (frontier_size) std::memcpy(h + i_fsize, frontier_size, 4 * nn); else std::memset(h + i_fsize, 0, 4 * nn);
+    if (blacklisted) std::memcpy(h + i_black, blacklisted, nn); else std::memset(h + i_black, 0, nn);
+    if (achievable_in) std::memcpy(h + i_achin, achievable_in, nn); else std::memset(h + i_achin, 1, nn);
+    if (cap > n) {                                              // the dummies: blacklisted, at the origin, nothing else
+        std::memset(h + i_goal + 24 * nn, 0, 24 * (cc - nn));
+        if (rank) { std::memset(h + i_len + 8 * nn, 0, 8 * (cc - nn)); std::memset(h + i_head + 8 * nn, 0, 8 * (cc - nn)); }
+        std::memset(h + i_fsize + 4 * nn, 0, 4 * (cc - nn));
+        std::memset(h + i_black + nn, 1, cc - nn);
+        std::memset(h + i_achin + nn, 1, cc - nn);
+    }
+    char *din = c->d_in.p, *dout = c->d_out.p;
+    auto enqueue = [&]() -> int {
+        FS_HIP(c, hipMemcpyAsync(din, c->h_in.p, total_in, hipMemcpyHostToDevice, c->stream));
+        const double *d_goal = reinterpret_cast<const double *>(din + i_goal);
+        const int32_t *d_fsize = reinterpret_cast<const int32_t *>(din + i_fsize);
+        const uint8_t *d_black = reinterpret_cast<const uint8_t *>(din + i_black), *d_achin = reinterpret_cast<const uint8_t *>(din + i_achin);
+        fs_record *d_rec = reinterpret_cast<fs_record *>(dout + o_rec);
+        int r = with_fim ? fs_score_candidates_dev(c, cap, d_goal, d_fsize, d_black, d_achin, d_rec)
+                         : arrival_records_dev(c, cap, d_goal, d_fsize, d_black, d_achin, d_rec);
+        if (r) return r;
+        if (rank) {
+            r = fs_rank_candidates_dev(c, cap, d_rec, d_black, reinterpret_cast<const double *>(din + i_len), reinterpret_cast<const double *>(din + i_head),
+                                       alpha, beta, max_vx, max_wz, reinterpret_cast<double *>(dout + o_cost), reinterpret_cast<double *>(dout + o_au),
+                                       reinterpret_cast<double *>(dout + o_du), reinterpret_cast<int32_t *>(dout + o_order), reinterpret_cast<int32_t *>(dout + o_err));
+            if (r) return r;
+        }
+        FS_HIP(c, hipMemcpyAsync(c->h_out.p, dout, rank ? total_out : sizeof(fs_record) * cc, hipMemcpyDeviceToHost, c->stream));
+        return FS_OK;
+    };
+    if (graphed) {
+        // what a captured sequence has baked in besides the pointers: the bucket, which kernels run, the ranking's parameters
+        uint64_t key = ((uint64_t)cap << 8) | (with_fim ? 1u : 0u) | (rank ? 2u : 0u) | (1ull << 40);
+        if (rank) {
+            const double prm[4] = {alpha, beta, max_vx, max_wz};
+            uint64_t hsh = 1469598103934665603ull;
+            for (size_t k = 0; k < sizeof prm; ++k) hsh = (hsh ^ reinterpret_cast<const unsigned char *>(prm)[k]) * 1099511628211ull;
+            key ^= hsh << 41;
+        }
+        rc = run_maybe_graphed(c, key, enqueue);
+    } else {
+        rc = enqueue();
+    }
+    const hipError_t e_sync = hipStreamSynchronize(c->stream);      // (also after a failure: what was queued out of h_in has landed)
+    if (rc) return rc;
+    if (e_sync != hipSuccess) return fail(c, FS_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e_sync));
+    const char *ho = c->h_out.p;
+    std::memcpy(records, ho + o_rec, sizeof(fs_record) * nn);
+    if (rank) {
+        std::memcpy(weighted_cost, ho + o_cost, 8 * nn);
+        if (arrival_utility) std::memcpy(arrival_utility, ho + o_au, 8 * nn);
+        if (distance_utility) std::memcpy(distance_utility, ho + o_du, 8 * nn);
+        if (order) std::memcpy(order, ho + o_order, 4 * nn);       // (stable sort: the dummies come after every real candidate)
+        int32_t err = 0;
+        std::memcpy(&err, ho + o_err, 4);
+        if (err) return fail(c, FS_E_RANGE, "utility outside [0,1] (the reference throws: FrontierCostsManager.cpp:148-149,173-174)");
+    }
+    return FS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int fs_score_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
                         const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records)
 {
     if (!c) return FS_E_INVALID;
     if (n < 0 || (n > 0 && (!goal_xyz || !records))) return fail(c, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    // up to FS_GRAPH_MAX_N candidates — the reference's operating point — the call is one captured launch graph
+    if (c->opt_graph && !c->timing && n <= FS_GRAPH_MAX_N)
+        return frontier_costs_core(c, n, goal_xyz, frontier_size, blacklisted, achievable_in, nullptr, nullptr, 0, 0, 0, 0, true,
+                                   records, nullptr, nullptr, nullptr, nullptr);
     const int rc = fs_score_candidates_begin(c, n, goal_xyz, frontier_size, blacklisted, achievable_in);
     if (rc) return rc;
     return fs_score_candidates_end(c, n, records);
+}
+
+int fs_get_frontier_costs(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size, const uint8_t *blacklisted,
+                          const uint8_t *achievable_in, const double *path_length, const double *path_heading,
+                          double alpha, double beta, double max_vx, double max_wz, int with_fisher_information,
+                          fs_record *records, double *weighted_cost, double *arrival_utility, double *distance_utility, int32_t *order)
+{
+    if (!c) return FS_E_INVALID;
+    if (n < 0 || (n > 0 && (!goal_xyz || !path_length || !path_heading || !records || !weighted_cost))) return fail(c, FS_E_INVALID, "null pointer");
+    if (n == 0) return FS_OK;
+    return frontier_costs_core(c, n, goal_xyz, frontier_size, blacklisted, achievable_in, path_length, path_heading, alpha, beta, max_vx, max_wz,
+                               with_fisher_information != 0, records, weighted_cost, arrival_utility, distance_utility, order);
 }
 
 // ------------------------------------------------------------------ utility + ranking

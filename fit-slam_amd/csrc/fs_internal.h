@@ -73,6 +73,7 @@ struct FsRayArgs {
     uint8_t *achievable;
     const float *yawR;         // [n_windows][9] rotation per argmax index (for pose12)
     float *pose12;             // [n][12] R (row-major) + t of the pose (goal, best yaw), or nullptr
+    fs_record *records;        // [n] arrival-only records (Fisher columns zero), or nullptr: what fs_get_frontier_costs ranks when no FI is asked for
 };
 
 // ---- generic segment tracing (getTracedCells + a RayTracedCells visitor per segment)
@@ -212,6 +213,8 @@ struct FsFimArgs {
 #define FS_SLOT_CNT_SAT  1024u  // counts beyond this contribute exactly 0.0f anyway
 #define FS_MAX_TABLE_CELLS ((1u << (32 - FS_SLOT_CNT_BITS)) - 2u)
 
+
+extern uint64_t fs_alloc_generation;   // bumped by every device / page-locked (re)allocation of the library (fs_capi.hip): launch graphs hold raw pointers
 
 // launchers (defined in the .hip files)
 hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s);

@@ -119,6 +119,7 @@ hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *
     if (need > *scratch_bytes) {
         if (*scratch) (void)hipFree(*scratch);
         *scratch = nullptr; *scratch_bytes = 0;
+        ++fs_alloc_generation;
         e = hipMalloc(scratch, need);
         if (e != hipSuccess) return e;
         *scratch_bytes = need;

@@ -416,6 +416,11 @@ void fs_raymarch_kernel(const FsRayArgs a)
         if (lane == 0) {
             a.arrival[c] = 0; a.argmax[c] = 0; a.yaw[c] = 0.0; a.achievable[c] = ach;
             a.status[c] = black ? FS_STATUS_BLACKLISTED : FS_STATUS_OFF_MAP;
+            if (a.records) {
+                fs_record r{};
+                r.flags = (ach ? FS_FLAG_ACHIEVABLE : 0u) | ((uint32_t)(black ? FS_STATUS_BLACKLISTED : FS_STATUS_OFF_MAP) << 8);
+                a.records[c] = r;
+            }
         }
         return;
     }
@@ -465,6 +470,13 @@ void fs_raymarch_kernel(const FsRayArgs a)
         a.yaw[c] = ((double)best_i * a.delta_theta) + a.half_fov;   // :119, half_fov = CAMERA_FOV / 2
         a.achievable[c] = ach;
         a.status[c] = FS_STATUS_OK;
+        if (a.records) {
+            fs_record r{};
+            r.arrival = best; r.argmax = best_i;
+            r.yaw = (float)(((double)best_i * a.delta_theta) + a.half_fov);
+            r.flags = (ach ? FS_FLAG_ACHIEVABLE : 0u) | ((uint32_t)FS_STATUS_OK << 8);
+            a.records[c] = r;
+        }
     }
     // pose (goal, best yaw) of the Fisher-information stage as one 48-byte record: rotation of
     // orientationAroundZAxis(yaw) (table indexed by the argmax) and the float32 translation of getTransformFromPose

@@ -129,6 +129,7 @@ hipError_t fs_launch_sort_candidates(int32_t n, const double *d_goal, const FsGr
     if (need > *scratch_bytes) {
         if (*scratch) (void)hipFree(*scratch);
         *scratch = nullptr; *scratch_bytes = 0;
+        ++fs_alloc_generation;
         hipError_t e = hipMalloc(scratch, need);
         if (e != hipSuccess) return e;
         *scratch_bytes = need;

@@ -326,6 +326,21 @@ int fs_rank_candidates(fs_ctx *ctx, int32_t n, const fs_record *records, const u
                        double *weighted_cost, double *arrival_utility, double *distance_utility,
                        int32_t *order);
 
+/* The whole of bool CostAssigner::getFrontierCosts(req, res) (DEP/include/.../CostAssigner.hpp:43-59,70; DEP/src/CostAssigner.cpp:73-119)
+ * — FrontierCostsManager::assignCosts' arrival information for every frontier (DEP/src/FrontierCostsManager.cpp:74-119) followed by
+ * its U1 block (:126-205) — as ONE call: frontier list and the planner's path columns in, scored and ranked candidates out; one
+ * transfer each way and one synchronisation, the records never visit the host between scoring and ranking.  Up to 1024
+ * frontiers (the reference handles tens per tick) the device-side sequence is a captured launch graph that is replayed with a
+ * single launch ("graph" option of fitslam_frontier_dev.h).
+ *   path_length, path_heading [n]  what the planner set on each frontier (Frontier::setPathLength / setPathHeading; inputs here)
+ *   with_fisher_information        0: arrival information only — what the reference's assignCosts uses; the Fisher columns of the
+ *                                  records stay zero.  1: also the Fisher information at the pose (goal, best yaw), as fs_score_candidates
+ *   records [n]; weighted_cost [n]; arrival_utility, distance_utility, order [n] or NULL.  FS_E_RANGE where the reference throws. */
+int fs_get_frontier_costs(fs_ctx *ctx, int32_t n, const double *goal_xyz, const int32_t *frontier_size, const uint8_t *blacklisted,
+                          const uint8_t *achievable_in, const double *path_length, const double *path_heading,
+                          double alpha, double beta, double max_vx, double max_wz, int with_fisher_information,
+                          fs_record *records, double *weighted_cost, double *arrival_utility, double *distance_utility, int32_t *order);
+
 /* Same, behind the scoring call on the device: every pointer is device memory (d_records = the records fs_score_candidates_dev
  * wrote, or the receive buffer of the all-gather), launched on the context's stream and NOT waited for — score and rank run
  * back to back without the records ever visiting the host ("fused after scoring").  d_arrival_utility,
