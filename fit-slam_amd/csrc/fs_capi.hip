@@ -52,26 +52,35 @@ struct DevBuf {
 // page-locked staging memory of a context: copies from / to it are true DMA transfers that overlap with the host, copies
 // from pageable user memory are staged by the runtime in small synchronous pieces (measured on C3's 20 k candidates: 1.29 ms per
 // fs_score_candidates call with pageable copies of the three input columns and the records)
+// The buffer is also MAPPED into the device's address space (`dev`, nullptr if the runtime refuses): a small call lets its
+// kernels read the candidate columns from it and write the results into it directly — a transfer of a few hundred bytes costs
+// 4-5 us as an operation of its own on the stream (measured: five result columns against two, 46 against 33 us per one-pose
+// call), a handful of PCIe reads and posted writes inside kernels that run anyway cost nothing that shows.
 struct PinnedBuf {
-    char *p = nullptr;
+    char *p = nullptr, *dev = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
         if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
+        p = nullptr; dev = nullptr; cap = 0;
         const size_t want = std::max<size_t>(bytes, 4096);
         ++fs_alloc_generation;
-        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        cap = want;
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess) dev = static_cast<char *>(d);
+        else (void)hipGetLastError();
+        return hipSuccess;
     }
     void release()
     {
         if (p) (void)hipHostFree(p);
-        p = nullptr; cap = 0;
+        p = nullptr; dev = nullptr; cap = 0;
     }
 };
+#define FS_ZERO_COPY_MAX_N 1024   // candidates / poses up to which a host-buffer call reads and writes the mapped staging buffers in place
 
 struct TimedLaunch {
     int kind;
@@ -199,6 +208,7 @@ struct fs_ctx {
     int opt_layout = 0;            // "ray.layout": 0 by ray length, 1 row-major byte walk, 2 class-image walk
 
     // launch graphs of the small host-buffer calls ("graph" option; off while kernel timing is on)
+    bool opt_zero_copy = true;     // "zerocopy": small host-buffer calls read / write the mapped page-locked buffers in place
     bool opt_graph = false;        // measured 5-7 us SLOWER per call than plain launches on ROCm 7.2 (profiles/r04/small_call_graphs.json): off by default
     uint64_t epoch = 1;
     std::map<uint64_t, GraphEntry> graphs;
@@ -1091,11 +1101,14 @@ static int upload_candidates(fs_ctx *c, int32_t n, const double *goal_xyz, const
     if (black) std::memcpy(c->h_in.p + o_black, black, nn);
     if (achin) std::memcpy(c->h_in.p + o_achin, achin, nn);
     const size_t used = achin ? total : (black ? o_black + pad : (fsize ? o_fsize + 4 * nn : 24 * nn));
-    FS_HIP(c, hipMemcpyAsync(c->d_in.p, c->h_in.p, used, hipMemcpyHostToDevice, c->stream));
-    c->in_goal = reinterpret_cast<const double *>(c->d_in.p + o_goal);
-    c->in_fsize = fsize ? reinterpret_cast<const int32_t *>(c->d_in.p + o_fsize) : nullptr;
-    c->in_black = black ? reinterpret_cast<const uint8_t *>(c->d_in.p + o_black) : nullptr;
-    c->in_achin = achin ? reinterpret_cast<const uint8_t *>(c->d_in.p + o_achin) : nullptr;
+    // a short list is read by the kernels where it lies (mapped page-locked memory): no transfer of its own
+    const bool in_place = c->opt_zero_copy && n <= FS_ZERO_COPY_MAX_N && c->h_in.dev;
+    const char *base = in_place ? c->h_in.dev : c->d_in.p;
+    if (!in_place) FS_HIP(c, hipMemcpyAsync(c->d_in.p, c->h_in.p, used, hipMemcpyHostToDevice, c->stream));
+    c->in_goal = reinterpret_cast<const double *>(base + o_goal);
+    c->in_fsize = fsize ? reinterpret_cast<const int32_t *>(base + o_fsize) : nullptr;
+    c->in_black = black ? reinterpret_cast<const uint8_t *>(base + o_black) : nullptr;
+    c->in_achin = achin ? reinterpret_cast<const uint8_t *>(base + o_achin) : nullptr;
     return FS_OK;
 }
 
@@ -1128,6 +1141,35 @@ int fs_score_arrival_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const i
     a.ray_counts = ray_counts ? c->d_raycounts.p : nullptr;
     a.arrival = c->d_arrival.p; a.argmax = c->d_argmax.p; a.status = c->d_status.p;
     a.yaw = c->d_yaw.p; a.achievable = c->d_ach.p;
+    // a short list: the kernel writes its five result columns straight into the mapped page-locked buffer (five transfers less;
+    // the per-ray counts, if asked for, are the one column large enough to keep its transfer)
+    {
+        const size_t nn0 = (size_t)n;
+        const size_t o_arr = 0, o_arg = o_arr + ((4 * nn0 + 15) & ~(size_t)15), o_st = o_arg + ((4 * nn0 + 15) & ~(size_t)15);
+        const size_t o_yaw = o_st + ((4 * nn0 + 15) & ~(size_t)15), o_ach = o_yaw + ((8 * nn0 + 15) & ~(size_t)15), o_rc = o_ach + ((nn0 + 15) & ~(size_t)15);
+        FS_HIP(c, c->h_out.ensure(o_rc + (ray_counts ? 4 * nn0 * per : 0)));
+        if (c->opt_zero_copy && n <= FS_ZERO_COPY_MAX_N && c->h_out.dev) {
+            char *hd = c->h_out.dev;
+            a.arrival = reinterpret_cast<int32_t *>(hd + o_arr); a.argmax = reinterpret_cast<int32_t *>(hd + o_arg);
+            a.status = reinterpret_cast<int32_t *>(hd + o_st); a.yaw = reinterpret_cast<double *>(hd + o_yaw);
+            a.achievable = reinterpret_cast<uint8_t *>(hd + o_ach);
+            rc = maybe_sort(c, a);
+            if (rc) return rc;
+            {
+                ScopedTimer t(c, 0);
+                FS_HIP(c, fs_launch_raymarch(a, c->stream));
+            }
+            c->arrival_pending.clear();
+            if (ray_counts) {
+                FS_HIP(c, hipMemcpyAsync(c->h_out.p + o_rc, c->d_raycounts.p, 4 * nn0 * per, hipMemcpyDeviceToHost, c->stream));
+                c->arrival_pending.push_back({ray_counts, o_rc, 4 * nn0 * per});
+            }
+            c->arrival_pending.push_back({arrival, o_arr, 4 * nn0}); c->arrival_pending.push_back({argmax, o_arg, 4 * nn0});
+            c->arrival_pending.push_back({status, o_st, 4 * nn0}); c->arrival_pending.push_back({yaw, o_yaw, 8 * nn0});
+            c->arrival_pending.push_back({achievable, o_ach, nn0});
+            return FS_OK;
+        }
+    }
     rc = maybe_sort(c, a);
     if (rc) return rc;
     {
@@ -1337,6 +1379,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (!c || !key) return FS_E_INVALID;
     ++c->epoch;                                            // (whatever the knob is, captured launch sequences are taken again)
     if (std::strcmp(key, "graph") == 0) { c->opt_graph = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "zerocopy") == 0) { c->opt_zero_copy = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.specialise") == 0) { c->opt_special = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.learn") == 0) { c->opt_learn = value != 0.0; return FS_OK; }
@@ -1531,10 +1574,28 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
     uint64_t col_mask = 0;
     for (int k = 0; k < 6; ++k) if (cols[k].host) { total += (cols[k].bytes + 15) & ~(size_t)15; col_mask |= 1ull << k; }
     FS_HIP(c, c->h_out.ensure(total));
+    // up to FS_ZERO_COPY_MAX_N poses the worker reads the pose records from, and the finish kernel writes the requested columns
+    // into, the mapped page-locked buffers: the call is three launches and one synchronisation, no transfers
+    const bool in_place = c->opt_zero_copy && n <= FS_ZERO_COPY_MAX_N && c->h_in.dev && c->h_out.dev;
     auto enqueue = [&]() -> int {
-        FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, c->h_in.p, nn * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        const int r = run_fim(c, a);
+        if (in_place) a.Rt = reinterpret_cast<const float *>(c->h_in.dev);
+        else FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, c->h_in.p, nn * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        bind_fim_outputs(c, a);
+        if (in_place) {
+            void **slot[6] = {reinterpret_cast<void **>(&a.info_ref), reinterpret_cast<void **>(&a.fim21), reinterpret_cast<void **>(&a.trace),
+                              reinterpret_cast<void **>(&a.logdet), reinterpret_cast<void **>(&a.n_visible), reinterpret_cast<void **>(&a.n_voxels)};
+            size_t o = 0;
+            for (int k = 0; k < 6; ++k) {
+                if (!cols[k].host) continue;
+                *slot[k] = c->h_out.dev + o;
+                o += (cols[k].bytes + 15) & ~(size_t)15;
+            }
+        }
+        int r = run_fim_tier1(c, a, nullptr, 0, a.n);
         if (r) return r;
+        r = run_fim_rest(c, a);
+        if (r) return r;
+        if (in_place) return FS_OK;
         size_t o = 0;
         for (const Col &col : cols) {
             if (!col.host) continue;
@@ -1544,7 +1605,7 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
         return FS_OK;
     };
     // ONE pose is isPoseSafe's call: its launch sequence is captured (per number of poses up to 4, requested columns, cull mode)
-    if (n <= 4) rc = run_maybe_graphed(c, (2ull << 40) | ((uint64_t)n << 8) | (col_mask << 1) | (uint64_t)(a.cull ? 1 : 0), enqueue);
+    if (n <= 4) rc = run_maybe_graphed(c, (2ull << 40) | ((uint64_t)n << 8) | (col_mask << 1) | (uint64_t)(a.cull ? 1 : 0) | (in_place ? 128u : 0u), enqueue);
     else rc = enqueue();
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     size_t off = 0;
@@ -1754,11 +1815,13 @@ int fs_score_candidates_begin(fs_ctx *c, int32_t n, const double *goal_xyz, cons
     rc = upload_candidates(c, n, goal_xyz, frontier_size, blacklisted, achievable_in);
     if (rc) return rc;
     FS_HIP(c, c->d_records.ensure(n));
-    rc = fs_score_candidates_dev(c, n, c->in_goal, c->in_fsize, c->in_black, c->in_achin,
-                                 c->d_records.p);
-    if (rc) return rc;
     FS_HIP(c, c->h_out.ensure(sizeof(fs_record) * (size_t)n));
-    FS_HIP(c, hipMemcpyAsync(c->h_out.p, c->d_records.p, sizeof(fs_record) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    // a short list: the finish kernel writes the records straight into the mapped page-locked buffer
+    const bool in_place = c->opt_zero_copy && n <= FS_ZERO_COPY_MAX_N && c->h_out.dev;
+    rc = fs_score_candidates_dev(c, n, c->in_goal, c->in_fsize, c->in_black, c->in_achin,
+                                 in_place ? reinterpret_cast<fs_record *>(c->h_out.dev) : c->d_records.p);
+    if (rc) return rc;
+    if (!in_place) FS_HIP(c, hipMemcpyAsync(c->h_out.p, c->d_records.p, sizeof(fs_record) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     return FS_OK;
 }
 
@@ -1835,9 +1898,11 @@ int frontier_costs_core(fs_ctx *c, int32_t n, const double *goal_xyz, const int3
         std::memset(h + i_black + nn, 1, cc - nn);
         std::memset(h + i_achin + nn, 1, cc - nn);
     }
-    char *din = c->d_in.p, *dout = c->d_out.p;
+    // a short list is read and its results are written where they lie, in the mapped page-locked buffers: no transfers at all
+    const bool in_place = c->opt_zero_copy && cap <= FS_ZERO_COPY_MAX_N && c->h_in.dev && c->h_out.dev;
+    char *din = in_place ? c->h_in.dev : c->d_in.p, *dout = in_place ? c->h_out.dev : c->d_out.p;
     auto enqueue = [&]() -> int {
-        FS_HIP(c, hipMemcpyAsync(din, c->h_in.p, total_in, hipMemcpyHostToDevice, c->stream));
+        if (!in_place) FS_HIP(c, hipMemcpyAsync(din, c->h_in.p, total_in, hipMemcpyHostToDevice, c->stream));
         const double *d_goal = reinterpret_cast<const double *>(din + i_goal);
         const int32_t *d_fsize = reinterpret_cast<const int32_t *>(din + i_fsize);
         const uint8_t *d_black = reinterpret_cast<const uint8_t *>(din + i_black), *d_achin = reinterpret_cast<const uint8_t *>(din + i_achin);
@@ -1851,12 +1916,12 @@ int frontier_costs_core(fs_ctx *c, int32_t n, const double *goal_xyz, const int3
                                        reinterpret_cast<double *>(dout + o_du), reinterpret_cast<int32_t *>(dout + o_order), reinterpret_cast<int32_t *>(dout + o_err));
             if (r) return r;
         }
-        FS_HIP(c, hipMemcpyAsync(c->h_out.p, dout, rank ? total_out : sizeof(fs_record) * cc, hipMemcpyDeviceToHost, c->stream));
+        if (!in_place) FS_HIP(c, hipMemcpyAsync(c->h_out.p, dout, rank ? total_out : sizeof(fs_record) * cc, hipMemcpyDeviceToHost, c->stream));
         return FS_OK;
     };
     if (graphed) {
         // what a captured sequence has baked in besides the pointers: the bucket, which kernels run, the ranking's parameters
-        uint64_t key = ((uint64_t)cap << 8) | (with_fim ? 1u : 0u) | (rank ? 2u : 0u) | (1ull << 40);
+        uint64_t key = ((uint64_t)cap << 8) | (with_fim ? 1u : 0u) | (rank ? 2u : 0u) | (in_place ? 4u : 0u) | (1ull << 40);
         if (rank) {
             const double prm[4] = {alpha, beta, max_vx, max_wz};
             uint64_t hsh = 1469598103934665603ull;

@@ -38,6 +38,10 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * "fim.learn" (default 1): 0 = predict the passes with the fixed cap alone.  The number of passes decides the order in which a
  * candidate's float32 terms are added, so with learning on the LAST BITS of info / trace / log det depend on the calls a
  * context has finished before (and, under fs_multi, on the member that scored the candidate); integers never do.
+ * "zerocopy" (default 1): host-buffer calls of up to 1024 candidates / poses let their kernels read the inputs from, and write
+ * the results into, the context's page-locked staging buffers, which are mapped into the device's address space — no transfer
+ * operations on the stream (one pose with five result columns: 66 -> 50 us; profiles/r04/small_call_in_place_staging.json);
+ * 0 = transfers, as every larger call uses.  Identical results.
  * "graph" (default 0): 1 = the small host-buffer calls (fs_score_candidates / fs_get_frontier_costs up to 1024 candidates, fs_score_fim
  * up to 4 poses) replay a captured launch graph instead of launching their kernels one by one (identical results).  Measured
  * 5-7 us slower per call than plain launches on ROCm 7.2 (profiles/r04/small_call_graphs.json), hence off; never used while

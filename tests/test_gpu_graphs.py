@@ -155,3 +155,34 @@ def test_get_frontier_costs_matches_oracle(fs, oracle, scorer, ref_table, n, wit
             scorer.get_frontier_costs(w.goals, plen, phead, w.frontier_size, w.blacklisted, with_fim=with_fim)
         assert e.value.code == fs.capi.FS_E_RANGE
     scorer.set_arrival_limits(400.0, 40.0)
+
+
+def test_in_place_staging_equals_transfers(fs, oracle, scorer, ref_table):
+    """Up to 1024 candidates / poses a host-buffer call reads its inputs from, and writes its results into, the mapped page-locked
+    staging buffers ("zerocopy" 1, the default); 0 moves them with transfers as every larger call does.  Same results."""
+    w = fs.synth.make_workload("C2", n_cand=900)
+    _stage(scorer, w)
+    scorer.set_option("graph", 0)
+    scorer.set_arrival_limits(4000.0, 40.0)
+    g, f, b = w.goals, w.frontier_size, w.blacklisted
+    poses = oracle.poses_from_yaw(w.goals[:50], np.linspace(-3, 3, 50))
+    rng = np.random.default_rng(1)
+    plen, phead = rng.uniform(0.5, 30.0, size=900), rng.uniform(0.0, np.pi, size=900)
+    out = {}
+    for z in (1, 0):
+        scorer.set_option("zerocopy", z)
+        out[z] = dict(rec=scorer.score_candidates(g, f, b), arr=scorer.score_arrival(g, f, b), fim=scorer.score_fim(poses),
+                      io=scorer.score_fim(poses, info_only=True), costs=scorer.get_frontier_costs(g, plen, phead, f, b, with_fim=True),
+                      one=scorer.score_candidates(g[:1], f[:1], b[:1]))
+    scorer.set_option("zerocopy", 1)
+    _same(out[1]["rec"], out[0]["rec"]); _same(out[1]["one"], out[0]["one"]); _same(out[1]["costs"]["records"], out[0]["costs"]["records"])
+    for k in ("arrival", "argmax", "status", "achievable", "yaw", "ray_counts"):
+        np.testing.assert_array_equal(out[1]["arr"][k], out[0]["arr"][k], err_msg=k)
+    for k in ("n_visible", "n_voxels"):
+        np.testing.assert_array_equal(out[1]["fim"][k], out[0]["fim"][k])
+    np.testing.assert_array_equal(out[1]["io"]["n_voxels"], out[0]["io"]["n_voxels"])
+    for k in ("info_ref", "trace", "logdet", "fim21"):
+        np.testing.assert_allclose(out[1]["fim"][k], out[0]["fim"][k], rtol=5e-6, atol=1e-5)
+    np.testing.assert_allclose(out[1]["io"]["info_ref"], out[0]["io"]["info_ref"], rtol=5e-6, atol=1e-6)
+    for k in ("weighted_cost", "arrival_utility", "distance_utility", "order"):
+        np.testing.assert_array_equal(out[1]["costs"][k], out[0]["costs"][k], err_msg=k)
