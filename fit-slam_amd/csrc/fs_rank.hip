@@ -10,6 +10,7 @@
 // order-preserving integer image of the double).
 #include "fs_internal.h"
 
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -32,14 +33,18 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
-// reset() + recomputeNormalizationFactors over the list (CostCalculator.hpp:110-116, CostCalculator.cpp:512-520)
+// reset() + recomputeNormalizationFactors over the list (CostCalculator.hpp:110-116, CostCalculator.cpp:512-520).
+// Up to FS_NORM_BLOCKS workgroups reduce a slice each into `partial`; the last one to finish (a ticket that it resets to zero
+// for the next call) folds the partials into `out` — min / max are exact whatever the order, so the result does not depend on it.
+#define FS_NORM_BLOCKS 64
 __global__ __launch_bounds__(1024)
 void fs_rank_norm_kernel(int32_t n, const fs_record *rec, const uint8_t *black, const double *len,
-                         RankNorm *out, int32_t *err)
+                         RankNorm *out, RankNorm *partial, unsigned int *ticket, int32_t *err)
 {
     __shared__ double s_min_d[16], s_max_d[16], s_min_i[16];
+    __shared__ bool s_last;
     double min_d = FS_DBL_MAX, max_d = -1.0, min_i = FS_DBL_MAX;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         if (black && black[i]) continue;
         if (!(rec[i].flags & FS_FLAG_ACHIEVABLE)) continue;
         const double l = len[i], a = (double)rec[i].arrival;
@@ -57,8 +62,25 @@ void fs_rank_norm_kernel(int32_t n, const fs_record *rec, const uint8_t *black, 
             max_d = (max_d < s_max_d[w]) ? s_max_d[w] : max_d;
             min_i = (s_min_i[w] < min_i) ? s_min_i[w] : min_i;
         }
-        out->min_dist = min_d; out->max_dist = max_d; out->min_info = min_i;
+        partial[blockIdx.x] = RankNorm{min_d, max_d, min_i};
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        RankNorm r{FS_DBL_MAX, -1.0, FS_DBL_MAX};
+        for (unsigned int b = 0; b < gridDim.x; ++b) {
+            const volatile RankNorm *p = partial + b;
+            const double a = p->min_dist, m = p->max_dist, i = p->min_info;
+            r.min_dist = (a < r.min_dist) ? a : r.min_dist;
+            r.max_dist = (r.max_dist < m) ? m : r.max_dist;
+            r.min_info = (i < r.min_info) ? i : r.min_info;
+        }
+        *out = r;
         *err = 0;
+        *ticket = 0u;
     }
 }
 
@@ -111,7 +133,7 @@ hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *
     hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
                                              (int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, 0, 64, s);
     if (e != hipSuccess) return e;
-    const size_t off_keys_in = 256;
+    const size_t off_keys_in = 256 + sizeof(RankNorm) * FS_NORM_BLOCKS;      // [norm | ticket ... | partials][keys ...]
     const size_t off_keys_out = off_keys_in + ((sizeof(uint64_t) * (size_t)n + 255) & ~(size_t)255);
     const size_t off_vals_in = off_keys_out + ((sizeof(uint64_t) * (size_t)n + 255) & ~(size_t)255);
     const size_t off_temp = off_vals_in + ((sizeof(int32_t) * (size_t)n + 255) & ~(size_t)255);
@@ -123,6 +145,8 @@ hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *
         e = hipMalloc(scratch, need);
         if (e != hipSuccess) return e;
         *scratch_bytes = need;
+        e = hipMemsetAsync(*scratch, 0, 256, s);                  // the norm kernel's ticket starts at zero (and returns there after every call)
+        if (e != hipSuccess) return e;
     }
     char *base = static_cast<char *>(*scratch);
     RankNorm *norm = reinterpret_cast<RankNorm *>(base);
@@ -131,7 +155,10 @@ hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *
     int32_t *vals_in = reinterpret_cast<int32_t *>(base + off_vals_in);
     void *temp = base + off_temp;
 
-    hipLaunchKernelGGL(fs_rank_norm_kernel, dim3(1), dim3(1024), 0, s, n, d_records, d_black, d_len, norm, d_err);
+    unsigned int *ticket = reinterpret_cast<unsigned int *>(base + 128);
+    RankNorm *partial = reinterpret_cast<RankNorm *>(base + 256);
+    const int norm_blocks = std::min(FS_NORM_BLOCKS, (n + 1023) / 1024);
+    hipLaunchKernelGGL(fs_rank_norm_kernel, dim3(norm_blocks), dim3(1024), 0, s, n, d_records, d_black, d_len, norm, partial, ticket, d_err);
     hipLaunchKernelGGL(fs_rank_cost_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d_records, d_black, d_len,
                        d_head, norm, alpha, beta, max_vx, max_wz, max_gt, d_cost, d_au, d_du, keys_in, vals_in, d_err);
     e = hipGetLastError();

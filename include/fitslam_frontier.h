@@ -332,7 +332,10 @@ int fs_rank_candidates(fs_ctx *ctx, int32_t n, const fs_record *records, const u
  * transfer each way and one synchronisation, the records never visit the host between scoring and ranking.  Up to 1024
  * frontiers (the reference handles tens per tick) the device-side sequence is a captured launch graph that is replayed with a
  * single launch ("graph" option of fitslam_frontier_dev.h).
- *   path_length, path_heading [n]  what the planner set on each frontier (Frontier::setPathLength / setPathHeading; inputs here)
+ *   path_length, path_heading [n]  what the planner set on each frontier (Frontier::setPathLength / setPathHeading; inputs here).
+ *                                  The reference plans a frontier only once its arrival information has left it achievable
+ *                                  (FrontierCostsManager.cpp:88-91); here the columns come first — those of a frontier that turns
+ *                                  out unachievable (or is blacklisted) are never read: same costs, the plan was spare work
  *   with_fisher_information        0: arrival information only — what the reference's assignCosts uses; the Fisher columns of the
  *                                  records stay zero.  1: also the Fisher information at the pose (goal, best yaw), as fs_score_candidates
  *   records [n]; weighted_cost [n]; arrival_utility, distance_utility, order [n] or NULL.  FS_E_RANGE where the reference throws. */
