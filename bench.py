@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="fs_set_option knobs, e.g. ray.layout=2")
     ap.add_argument("--latency", action="store_true", help="the drop-in operating point instead of the throughput line: p50 / p99 of ONE fs_score_candidates call (host buffers in, records out, synchronised) at 1 / 50 / 200 / 2000 frontiers on REF2D and C1, of fs_score_fim(n = 1) and of fs_frontier_clusters on a 512^2 costmap, each with the oracle's single-thread time beside it")
     ap.add_argument("--latency-calls", type=int, default=300, help="calls per latency figure")
+    ap.add_argument("--rehearse-multi", action="store_true", help="one rank, but through every code path of the N > 1 run: a one-rank RCCL group, the asynchronous all-gather in every step, the ranking on the gathered list, the multi_gpu keys and the block-sampled parity gate (what a one-GPU box can rehearse of the multi-GPU line; never a scaling figure)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: the ranks meet over gloo, all-gather a dummy record block and rank 0 prints a line marked dry_run (no value)")
     return ap.parse_args(argv)
 
@@ -479,12 +480,15 @@ def run_rank(args) -> int:
     dev_index = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    multi_path = world > 1 or args.rehearse_multi                  # the N > 1 data path (a one-rank group under --rehearse-multi)
+    if multi_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         print(f"[bench] rank {rank}/{world} on cuda:{dev_index} ({args.backend})", file=sys.stderr, flush=True)
 
     fs = importlib.import_module("fit-slam_amd")
@@ -572,7 +576,7 @@ def run_rank(args) -> int:
                 pending[b].wait()                                    # (on streams[c]: the scorer below overwrites the buffer that gather read)
                 pending[b] = None
             scs[c].score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_rec.data_ptr())
-            if world > 1:
+            if multi_path:
                 if args.backend == "nccl":
                     state["full"], pending[b] = shard.gather_records(d_rec, n_total, async_op=True)
                     return state["full"]
@@ -590,7 +594,7 @@ def run_rank(args) -> int:
                 pending[b] = None
         torch.cuda.synchronize(dev)                                  # every stream of the device
         t_ready = time.perf_counter()
-        if world > 1:
+        if multi_path:
             dist.barrier()
             torch.cuda.synchronize(dev)
         return t_ready
@@ -647,7 +651,7 @@ def run_rank(args) -> int:
     #    (DESIGN.md 4.1); the timed loop scores one list over and over, so its map is perfectly trained.  A call whose
     #    predecessor recorded nothing (option sort.costmap off for one call) sees the empty map of a first call on a new snapshot.
     extra = {}
-    if world == 1 and not args.no_parity:
+    if not multi_path and not args.no_parity:
         g_h, f_h, b_h = blk_goals, blk_fsize, blk_black
         for _ in range(3):
             sc.score_candidates(g_h, f_h, b_h)
@@ -690,7 +694,7 @@ def run_rank(args) -> int:
         extra["rank_candidates_call"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3,
                                          "note": "fs_rank_candidates over one step's records: utilities, weighted cost and order, host columns both ways"}
 
-    if world == 1 and not args.no_parity:
+    if not multi_path and not args.no_parity:
         extra["reference_request_visibility" if args.fim_angle < np.pi else "build_cone_visibility"] = other_visibility(
             args, sc, w, n_local, d_goal, d_fsize, d_black, torch.zeros_like(d_recs[0]), dev, mx, arrival_kw)
 
@@ -700,7 +704,7 @@ def run_rank(args) -> int:
     # straight-line distance from the map's centre and the bearing as heading.  One block of K steps, same bracketing; reported
     # next to `value`, never instead of it.  (Path columns: see below.)
     ranked = None
-    if world == 1 or args.backend == "nccl":
+    if not multi_path or args.backend == "nccl":
         # (a function of the list index alone — a low-discrepancy sequence over [0.5, 30] m and [0, pi] rad — so that no rank
         # needs the other ranks' goal points and the columns are the same at every N)
         idx = np.arange(n_total, dtype=np.float64)
@@ -746,7 +750,7 @@ def run_rank(args) -> int:
     # ---- what a sub-linear curve would be made of (N > 1): every rank's own time per step, the spread with which the ranks
     # reach the closing barrier, and the all-gather by itself (blocking calls between an event pair on the scorer's stream)
     multi = None
-    if world > 1:
+    if multi_path:
         red_dev = dev if args.backend == "nccl" else "cpu"
         tmax = torch.tensor(block_s + ([ranked["dt"]] if ranked else []), dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -799,9 +803,9 @@ def run_rank(args) -> int:
         prof = counter_profile(wl_name, args.depth_cells)
         gpu_rec = shard.records_to_numpy(full) if not args.no_parity else None
         cpu, parity = (None, None)
-        if world == 1 and args.cpu_seconds > 0:
+        if not multi_path and args.cpu_seconds > 0:
             cpu, parity = cpu_baseline(w, arrival_kw, n_total, args.cpu_seconds, gpu_rec, mx, args.fim_angle)
-        elif world > 1 and gpu_rec is not None:
+        elif multi_path and gpu_rec is not None:
             # no CPU baseline at N > 1 (rank 0, N = 1 only), but the gathered list is still gated: 96 candidates out of every
             # rank's block against the oracle
             per_blk = 96
@@ -868,11 +872,11 @@ def run_rank(args) -> int:
                              "order_is_a_permutation": ranked["order_is_a_permutation"], "costs_ascending": ranked["costs_ascending"],
                              "note": "score (+ all-gather) + fs_rank_candidates_dev over the full list on the same stream, path columns resident; "
                                      "one block of K steps; never `value`"} if ranked else None),
-            "multi_gpu": multi,
+            "multi_gpu": multi, "rehearse_multi": bool(args.rehearse_multi) or None,
             "other_operating_points": extra or None,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi_path:
         dist.barrier()
         dist.destroy_process_group()
     for c in scs:

@@ -65,3 +65,25 @@ def test_scoring_then_rccl_all_gather_on_one_stream(fs):
             torch.cuda.set_stream(prev)
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_rehearses_the_multi_gpu_line_on_one_gpu():
+    """`bench.py --rehearse-multi`: one rank, but a real (one-rank) RCCL group and every code path the N > 1 run takes — the
+    asynchronous all-gather behind every step, fs_rank_candidates_dev on the gathered list, the multi_gpu keys (per-rank time,
+    barrier skew, the all-gather by itself) and the block-sampled parity gate.  Not a scaling figure; the proof that the first
+    real multi-GPU run will not die in code no one-GPU box had executed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-multi", "--workload", "C2", "--steps", "3", "--warmup", "2",
+                        "--repeats", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 1 and j["rehearse_multi"] is True and "nccl" in j["config"]["sharding"]
+    assert j["parity"]["ok"] and "rank blocks" in j["parity"]["sample"], j["parity"]
+    mg = j["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step"]) == 1 and mg["all_gather_ms"] > 0 and mg["barrier_skew_ms"] == 0.0
+    rs = j["ranked_step"]
+    assert rs["order_is_a_permutation"] and rs["costs_ascending"] and rs["range_error"] == 0 and rs["ms_per_step"] >= j["ms_per_step"] * 0.9
