@@ -485,10 +485,23 @@ def run_rank(args) -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout belongs to the one JSON line, so
+        # file descriptor 1 points at stderr until the group has done its first collective
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+            if args.backend == "nccl":
+                torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         print(f"[bench] rank {rank}/{world} on cuda:{dev_index} ({args.backend})", file=sys.stderr, flush=True)
 
     fs = importlib.import_module("fit-slam_amd")

@@ -80,7 +80,9 @@ def test_bench_rehearses_the_multi_gpu_line_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-multi", "--workload", "C2", "--steps", "3", "--warmup", "2",
                         "--repeats", "3"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1, out_lines[:5]                          # ONE line on stdout: RCCL's banner went to stderr
+    j = json.loads(out_lines[0])
     assert j["n_gpus"] == 1 and j["rehearse_multi"] is True and "nccl" in j["config"]["sharding"]
     assert j["parity"]["ok"] and "rank blocks" in j["parity"]["sample"], j["parity"]
     mg = j["multi_gpu"]
