@@ -158,11 +158,29 @@ __device__ __forceinline__ int voxel_part(const FsFimArgs &a, bool active, float
 //
 // INFO_ONLY: the caller asked for the reference's scalar alone (isPoseSafe reads nothing else, FisherInfoManager.cpp:83-100) — the
 // 6x6 block sums and the visible count are not accumulated.
-template <bool TABLE_FULL, bool INFO_ONLY>
+// WITH_SUMS false: likewise without the block sums — and COUNT_VIS false without the visible count — for the worker that adds
+// both at TEST time (cone off: see fim_worker, SUMS_AT_TEST).
+// The 6x6 block sums of one landmark per lane: (A, B) += P * (1, 1/n^2), s += p / n^2 with P = I - p^ p^T.  A lane with q = 0
+// (not visible, or at the camera centre) adds exact zeros to every sum.
+__device__ __forceinline__ void add_block_sums(Acc &acc, float px, float py, float pz, float q)
+{
+    const fs_f2 pxy = {px, py};
+    const fs_f2 qxy = pxy * (fs_f2){q, q};
+    const fs_f2 xxyy = pxy * qxy;
+    const float qy = qxy.y, qz = pz * q;
+    const float xx = xxyy.x, yy = xxyy.y, zz = pz * qz;
+    const float v[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
+    const fs_f2 one_q = {1.0f, q};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc.AB[i] = __builtin_elementwise_fma((fs_f2){v[i], v[i]}, one_q, acc.AB[i]);
+    acc.s01 += qxy; acc.s2 += qz;
+}
+
+template <bool TABLE_FULL, bool WITH_SUMS, bool COUNT_VIS = true>
 __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *table, const float *lfac, int bits, uint32_t max_probe,
                                               bool active, float px, float py, float pz, Acc &acc, bool &overflow)
 {
-    acc.nvis += active ? 1 : 0;
+    if (COUNT_VIS) acc.nvis += active ? 1 : 0;
     bool in_table;
     const uint32_t key = voxel_key(a, active, px, py, pz, in_table);
     const float info_t = FS_BOUND(key < (uint32_t)(a.tx * a.ty * a.tz), 1) ? ldg32(a.table, key) : 0.0f;
@@ -175,19 +193,10 @@ __device__ __forceinline__ void score_visible(const FsFimArgs &a, uint32_t *tabl
     hb &= bmask;      // whatever the hash returns, the bucket index stays inside the table
     uint4 bk = *reinterpret_cast<const uint4 *>(table + (hb << 2));
     resolve_pending<TABLE_FULL>(acc, lfac);                           // the previous call's landmarks
-    if (!INFO_ONLY) {
+    if (WITH_SUMS) {
         const float n2 = __fmaf_rn(px, px, __fmaf_rn(py, py, pz * pz));
         const float q = (active && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f;
-        const fs_f2 pxy = {px, py};
-        const fs_f2 qxy = pxy * (fs_f2){q, q};
-        const fs_f2 xxyy = pxy * qxy;
-        const float qy = qxy.y, qz = pz * q;
-        const float xx = xxyy.x, yy = xxyy.y, zz = pz * qz;
-        const float v[6] = {yy + zz, -(px * qy), -(px * qz), xx + zz, -(py * qz), xx + yy};
-        const fs_f2 one_q = {1.0f, q};
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc.AB[i] = __builtin_elementwise_fma((fs_f2){v[i], v[i]}, one_q, acc.AB[i]);
-        acc.s01 += qxy; acc.s2 += qz;
+        add_block_sums(acc, px, py, pz, q);
         // (pins the sums HERE, in the shadow of the bucket read: left alone the compiler sinks them below the probe)
         asm volatile("" : "+v"(acc.AB[0]), "+v"(acc.AB[1]), "+v"(acc.AB[2]), "+v"(acc.AB[3]), "+v"(acc.AB[4]), "+v"(acc.AB[5]), "+v"(acc.s01), "+v"(acc.s2));
     }
@@ -346,6 +355,13 @@ template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, int CONE, bool INFO_O
 __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits)
 {
     constexpr uint32_t fail_code = GLOBAL_TABLE ? 3u : 2u;
+    // With the cone off, roughly half of what is visible (everything within range) lies outside the lookup table's box — behind the
+    // camera, mostly — and only feeds the 6x6 sums and the visible count.  SUMS_AT_TEST adds those two for EVERY visible landmark
+    // right at the test (27 instructions per chunk tested, at whatever lane utilisation the chunk has) and queues only what can
+    // hit the table for the hash-table half of the scoring: the landmarks outside the box no longer pay a score call (165
+    // instructions per 64).  Pays when most tested landmarks are visible and many of them miss the table — the cone-off volume;
+    // with the cone nearly everything visible is in the box and the sums stay in the score call, at full lane utilisation.
+    constexpr bool SUMS_AT_TEST = (CONE == FS_CONE_OFF) && !INFO_ONLY && !GLOBAL_TABLE;
     constexpr int WAVES = THREADS / 64;
     constexpr int STRIDE = WAVES * 64;
     const uint32_t max_probe = GLOBAL_TABLE ? (1u << tier_bits) : FS_MAX_PROBE;   // bucket visits incl. re-reads
@@ -665,7 +681,15 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     // no cone: the sign of maxd2 - n2 alone; INFO_ONLY also drops what lies behind the table's near face (x index
                     // below the first lattice plane: a miss whatever y and z are)
                     m3 = maxd2_v - n2;
-                    if (INFO_ONLY) m3 = fminf(m3, px - xlo_v);
+                    if (SUMS_AT_TEST) {
+                        // the first pass of a candidate takes the sums and the count (later passes re-test the same landmarks)
+                        if (part == 0) {
+                            const bool in_range = m3 >= 0.0f;
+                            add_block_sums(acc, px, py, pz, (in_range && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f);
+                            acc.nvis += in_range ? 1 : 0;
+                        }
+                    }
+                    if (INFO_ONLY || SUMS_AT_TEST) m3 = fminf(m3, px - xlo_v);
                 } else if (CONE == FS_CONE_NARROW) {
                     // n2 <= maxd2 && px >= 0 && px2 >= cos2 * n2 in one value: the sign of a difference of two floats is exact, so each
                     // condition is "its difference is >= 0" and the three are "their minimum is >= 0" (-0.0 passes, as px >= 0 does):
@@ -695,7 +719,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #ifdef FS_FIM_STAMPS
                         const unsigned long long ts_ = __builtin_readcyclecounter();
 #endif
-                        score_visible<TABLE_FULL, INFO_ONLY>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
+                        score_visible<TABLE_FULL, !INFO_ONLY && !SUMS_AT_TEST, !SUMS_AT_TEST>(a, table, lfac, bits, max_probe, true, ex, ey, ez, acc, overflow);
 #ifdef FS_FIM_STAMPS
                         st[8] += __builtin_readcyclecounter() - ts_; st[9] += 1;
 #endif
@@ -745,7 +769,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // flush the queue remainder
         if (qcount > 0) {
             const bool have = lane < qcount;
-            score_visible<TABLE_FULL, INFO_ONLY>(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
+            score_visible<TABLE_FULL, !INFO_ONLY && !SUMS_AT_TEST, !SUMS_AT_TEST>(a, table, lfac, bits, max_probe, have, have ? qx[lane] : 1.0f, have ? qy[lane] : 0.0f, have ? qz[lane] : 0.0f, acc, overflow);
             qcount = 0;
         }
         if (overflow) raise_overflow();
