@@ -29,7 +29,7 @@ def main():
     sc = fs.FrontierScorer(0)
     full = oracle.Table.generate()
     rec = full.records
-    worst = 0.0
+    worst = worst_ld = 0.0
     t0 = time.time()
     for t in range(trials):
         # table: the reference one, or one with 30 % holes (the guarded kernels)
@@ -75,9 +75,25 @@ def main():
         tr = np.maximum(np.abs(want["trace"]), 1e-6)
         assert np.max(np.abs(got["trace"] - want["trace"]) / tr) <= REL, tag
         worst = max(worst, float(err.max()))
+        # D-optimality: plain 1e-4 of max(1, |log det|) plus the input-rounding floor cond(F) * 2^-24 (tests/test_gpu_parity.py)
+        both = np.isfinite(want["logdet"]) & np.isfinite(got["logdet"])
+        if both.any():
+            lam = np.linalg.eigvalsh(want["fim"][both])
+            cond = lam[:, -1] / np.maximum(lam[:, 0], 1e-300)
+            tol = REL * np.maximum(1.0, np.abs(want["logdet"][both])) + 2.0 ** -24 * cond
+            e_ld = np.abs(got["logdet"][both] - want["logdet"][both])
+            assert np.all(e_ld <= tol), (tag, float((e_ld / tol).max()))
+            worst_ld = max(worst_ld, float((e_ld / np.maximum(1.0, np.abs(want["logdet"][both])))[cond < 1e3].max(initial=0.0)))
+        # the same poses asked for info_ref alone: the INFO_ONLY worker (exact table-box cull in a general camera frame) where the
+        # table is finite and the cone common, the general one otherwise — n_voxels exactly, the information to the same tolerance
+        io = sc.score_fim(poses, info_only=True)
+        assert np.array_equal(io["n_voxels"], want["n_voxels"]), tag + " (info only)"
+        err_io = np.abs(io["info_ref"] - want["info_f64"]) / scale
+        assert np.all(err_io <= REL + drift), (tag + " (info only)", float(err_io.max()))
+        worst = max(worst, float(err_io.max()))
         print(f"ok {tag}  visible max {int(want['n_visible'].max())}  voxels max {int(want['n_voxels'].max())}  "
               f"multi-pass {sc.get_counter(4)} hbm {sc.get_counter(5)}  ({time.time() - t0:.0f} s)", flush=True)
-    print(f"{trials} trials passed, worst relative FI error {worst:.2e}")
+    print(f"{trials} trials passed, worst relative FI error {worst:.2e}, worst log det error at cond < 1e3 {worst_ld:.2e} of max(1, |ld|)")
 
 
 if __name__ == "__main__":
