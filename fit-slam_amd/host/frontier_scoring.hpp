@@ -307,14 +307,17 @@ public:
         min_arrival_info_per_frontier = std::numeric_limits<double>::max(); max_arrival_info_per_frontier = -1.0;
     }
     std::shared_ptr<ScoringContext> context() const { return ctx_; }
-
-private:
+    double deltaTheta() const { return DELTA_THETA; }
+    double cameraFov() const { return CAMERA_FOV; }
+    // polygon_xy_min_max of the current call (CostAssigner.cpp:148-165): a change re-stages the ray parameters
     void setPolygon(const std::vector<double> &p)
     {
         bool changed = false;
         for (int i = 0; i < 4; ++i) { changed |= (polygon_[i] != p[i]); polygon_[i] = p[i]; }
         if (changed) pushParams();
     }
+
+private:
     void pushParams()
     {
         fs_ray_params p{};
@@ -405,6 +408,70 @@ public:
             frontier_list[i]->setWeightedCost(cost[i]);
             frontier_list[i]->setCost("arrival_gain_utility", au[i]);
             frontier_list[i]->setCost("distance_utility", du[i]);
+        }
+        return true;
+    }
+
+    // The same contract as assignCosts through ONE device call (fs_get_frontier_costs): the planner runs FIRST — on every live
+    // frontier, as if achievable — and what it decides (a frontier it cannot reach: achievable = false) enters the call as
+    // achievable_in, which the arrival step can only clear further; the final flag is the AND of the same conditions in either
+    // order, and the path columns of a frontier that ends up unachievable are never read.  Costs, utilities, arrival information,
+    // orientation and achievability come out bit for bit as from assignCosts (tests/test_host_mirror.py); what differs is that the
+    // planner also plans frontiers the reference would have skipped (FrontierCostsManager.cpp:88-91) — spare work, same result.
+    bool assignCostsFused(std::vector<FrontierPtr> &frontier_list, std::vector<double> polygon_xy_min_max, Pose start_pose_w)
+    {
+        costCalculator_->reset();
+        costCalculator_->setMaxArrivalInformation();
+        if (frontier_list.size() == 0) return false;
+        if (polygon_xy_min_max.size() <= 0) return false;
+        for (size_t i = 0; i < frontier_list.size(); ++i)
+            for (size_t j = i + 1; j < frontier_list.size(); ++j)
+                if (frontier_list[i] == frontier_list[j]) throw std::runtime_error("Duplicate frontiers found.");
+        if (polygon_xy_min_max.size() >= 4) costCalculator_->setPolygon(polygon_xy_min_max);
+        const double dmax = std::numeric_limits<double>::max();
+        const int32_t n = (int32_t)frontier_list.size();
+        std::vector<uint8_t> black(n, 0), ach_in(n, 1);
+        std::vector<double> goal(3 * (size_t)n), plen(n, 0.0), phead(n, 0.0), cost(n), au(n), du(n);
+        std::vector<int32_t> fsize(n);
+        {
+            std::lock_guard<std::mutex> lock(blacklist_mutex_);
+            for (int32_t i = 0; i < n; ++i) black[i] = frontier_blacklist_.count(frontier_list[i].get()) > 0;
+        }
+        for (int32_t i = 0; i < n; ++i) {
+            auto &f = frontier_list[i];
+            const Point &g = f->getGoalPoint();
+            goal[3 * i] = g.x; goal[3 * i + 1] = g.y; goal[3 * i + 2] = g.z;
+            fsize[i] = f->getSize();
+            if (black[i]) continue;
+            if (planner_) planner_(start_pose_w, f);
+            else costCalculator_->setPlanForFrontierEuclidean(start_pose_w, f);
+            ach_in[i] = f->isAchievable();
+            if (ach_in[i]) { plen[i] = f->getPathLength(); phead[i] = f->getPathHeading(); }
+        }
+        std::vector<fs_record> rec(n);
+        auto ctx = costCalculator_->context();
+        const int rc = fs_get_frontier_costs(ctx->get(), n, goal.data(), fsize.data(), black.data(), ach_in.data(), plen.data(), phead.data(),
+                                             alpha_, beta_, max_vx_, max_wx_, /*with_fisher_information=*/0,
+                                             rec.data(), cost.data(), au.data(), du.data(), nullptr);
+        if (rc == FS_E_RANGE) throw std::runtime_error("Cost out of bounds");   // :148-149,173-174
+        ctx->check(rc, "fs_get_frontier_costs");
+        for (int32_t i = 0; i < n; ++i) {
+            auto &f = frontier_list[i];
+            if (black[i]) {                                                       // :77-86
+                f->setArrivalInformation(0.0); f->setGoalOrientation(0.0); f->setFisherInformation(0.0);
+                f->setPathLength(dmax); f->setPathLengthInM(dmax); f->setWeightedCost(dmax);
+            } else {
+                f->setArrivalInformation((double)rec[i].arrival);
+                f->setGoalOrientation(((double)rec[i].argmax * costCalculator_->deltaTheta()) + costCalculator_->cameraFov() / 2);   // CostCalculator.cpp:119, in double
+                if (FS_RECORD_STATUS(rec[i].flags) != FS_STATUS_OK) f->setGoalOrientation(0.0);                                    // :52-54
+                const bool achievable = (rec[i].flags & FS_FLAG_ACHIEVABLE) != 0;
+                f->setAchievability(achievable);
+                if (!achievable) { f->setPathLength(dmax); f->setPathLengthInM(dmax); f->setPathHeading(dmax); f->setFisherInformation(0); }
+                costCalculator_->recomputeNormalizationFactors(f);
+            }
+            f->setWeightedCost(cost[i]);
+            f->setCost("arrival_gain_utility", au[i]);
+            f->setCost("distance_utility", du[i]);
         }
         return true;
     }
@@ -831,7 +898,8 @@ public:
     bool getFrontierCosts(std::shared_ptr<GetFrontierCostsRequest> requestData, std::shared_ptr<GetFrontierCostsResponse> resultData)
     {
         frontierCostsManager_->setFrontierBlacklist(requestData->prohibited_frontiers);
-        const bool costsResult = frontierCostsManager_->assignCosts(requestData->frontier_list, polygon_xy_min_max_, requestData->start_pose.pose);
+        const bool costsResult = fused_ ? frontierCostsManager_->assignCostsFused(requestData->frontier_list, polygon_xy_min_max_, requestData->start_pose.pose)
+                                        : frontierCostsManager_->assignCosts(requestData->frontier_list, polygon_xy_min_max_, requestData->start_pose.pose);
         if (costsResult == false) { resultData->success = false; return resultData->success; }
         resultData->success = true;
         resultData->frontier_list.clear(); resultData->frontier_costs.clear();
@@ -846,8 +914,11 @@ public:
         return resultData->success;
     }
     std::shared_ptr<FrontierCostsManager> getCostManagerPtr() { return frontierCostsManager_; }
+    // true: the whole cost assignment as ONE device call (FrontierCostsManager::assignCostsFused); same results
+    void setFused(bool on) { fused_ = on; }
 
 private:
+    bool fused_ = false;
     std::shared_ptr<Costmap2D> costmap_;
     std::vector<double> polygon_xy_min_max_;
     std::shared_ptr<FrontierCostsManager> frontierCostsManager_;

@@ -69,6 +69,38 @@ int main(int argc, char **argv)
     printf("getFrontierCosts -> %d, %zu frontiers\n", (int)ok, res_->frontier_list.size());
     if (!ok || !res_->success) ++failures;
 
+    // the same request through the ONE-call path (fs_get_frontier_costs: planner first, then arrival + U1 in one device call) on
+    // fresh Frontier objects: every field the reference's response carries must come out bit for bit as above
+    {
+        auto req2 = std::make_shared<GetFrontierCostsRequest>();
+        auto res2 = std::make_shared<GetFrontierCostsResponse>();
+        req2->start_pose = req->start_pose;
+        for (int32_t i = 0; i < n; ++i) {
+            auto fr = std::make_shared<Frontier>();
+            fr->setUID((size_t)i + 1); fr->setSize(sizes[i]); fr->setGoalPoint(goals[2 * i], goals[2 * i + 1]);
+            req2->frontier_list.push_back(fr);
+            if (black[i]) req2->prohibited_frontiers.push_back(fr);
+        }
+        CostAssigner fused(ctx, costmap);
+        fused.updateBoundaryPolygon(boundary);
+        fused.setFused(true);
+        const bool ok2 = fused.getFrontierCosts(req2, res2);
+        int bad = (ok2 && res2->success) ? 0 : 1;
+        for (int32_t i = 0; i < n && ok2; ++i) {
+            const auto &p = res_->frontier_list[i];
+            const auto &q = res2->frontier_list[i];
+            bad += res2->frontier_costs[i] != res_->frontier_costs[i];
+            bad += res2->frontier_arrival_information[i] != res_->frontier_arrival_information[i];
+            bad += res2->frontier_distances[i] != res_->frontier_distances[i];
+            bad += q->isAchievable() != p->isAchievable();
+            bad += q->getGoalYaw() != p->getGoalYaw();
+            bad += q->getCost("arrival_gain_utility") != p->getCost("arrival_gain_utility");
+            bad += q->getCost("distance_utility") != p->getCost("distance_utility");
+        }
+        printf("getFrontierCosts through fs_get_frontier_costs: %d mismatches against the three-call path\n", bad);
+        if (bad) ++failures;
+    }
+
     // Fisher information at (goal, best yaw), built like isPoseSafe(Point, Point)
     roadmap_explorer::FisherInformationManager fim(ctx);
     failures += expect_throw("loadLookupTable(missing file)", [&] { fim.loadLookupTable("/nonexistent/fisher_information_lookup_table.dat"); });

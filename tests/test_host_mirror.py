@@ -83,6 +83,8 @@ def test_get_frontier_costs_and_pose_safety(fs, oracle, ref_table, tmp_path, see
     np.testing.assert_array_equal(recs[:, :2], fsr["goals"])
     np.testing.assert_array_equal(recs[:, 2], fsr["sizes"].astype(np.float64))
     assert "ShardedScorer({0,0}): 2 devices, 0 mismatches" in p.stdout
+    # CostAssigner::getFrontierCosts as ONE device call (planner first, fs_get_frontier_costs): every response field bit for bit
+    assert "getFrontierCosts through fs_get_frontier_costs: 0 mismatches" in p.stdout
 
     G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
     P = oracle.RayParams(polygon=poly32)
