@@ -140,3 +140,26 @@ def test_fused_path_yaw_only_worker(fs, oracle, scorer, ref_table, name, vis):
     scale = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
     assert np.max(np.abs(rec["info_ref"][ok] - fim["info_f64"][ok]) / scale) <= REL
     assert np.max(np.abs(rec["trace"][ok] - fim["trace"][ok]) / np.maximum(fim["trace"][ok], 1e-6)) <= REL
+
+
+def test_info_only_box_cull_follows_the_table_it_was_given(fs, oracle, scorer):
+    """The INFO_ONLY worker culls against the box of whatever lookup table is loaded, not against the reference's numbers: a small
+    table that reaches BEHIND the camera (x from -3 m) and is narrow in z, general orientations, cone off and on."""
+    bounds = np.array([-3.0, 6.0, -4.0, 4.0, -2.0, 2.0], dtype=np.float32)
+    table = oracle.Table.generate(bounds)
+    scorer.lookup_generate(bounds)
+    try:
+        w = fs.synth.make_workload("C2", n_cand=200)
+        rng = np.random.default_rng(47)
+        poses = oracle.poses_from_yaw(w.goals, rng.uniform(-np.pi, np.pi, size=200))
+        q = rng.normal(size=(100, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        poses[:100, 3:] = q
+        scorer.upload_landmarks(w.landmarks)
+        for vis in (REF_REQUEST, (14.0, 1.0), (5.0, 4.0)):
+            scorer.set_fim_params(*vis)
+            want = oracle.pose_information(table, w.landmarks, poses, vis[0], vis[1], n_threads=8)
+            assert want["n_voxels"].max() > 50
+            _both_workers(scorer, poses, want)
+    finally:
+        scorer.lookup_generate()
+        scorer.set_fim_params(14.0, 1.0)
