@@ -219,7 +219,11 @@ int fs_set_fim_params(fs_ctx *ctx, const fs_fim_params *p);
  *   pose7     [n][7] position xyz + orientation quaternion xyzw (geometry_msgs::Pose order)
  *   info_ref  [n]    the reference scalar: sum of table value x crowding factor over visible landmarks
  *   fim21     [n][21] upper triangle (row-major) of the unit-weight 6x6 FIM, or NULL
- *   trace, logdet [n] or NULL;  n_visible, n_voxels [n] or NULL */
+ *   trace, logdet [n] or NULL;  n_visible, n_voxels [n] or NULL
+ * A call that passes NULL for fim21, trace, logdet and n_visible — i.e. asks for what isPoseSafe itself reads (:83-100), plus
+ * n_voxels if wanted — is served by a worker that neither accumulates the 6x6 sums nor looks at landmarks outside the lookup
+ * table's box (a table miss contributes nothing, :90-94): same info_ref (to the last bits) and the same n_voxels, less work.
+ * The visibility volume is fs_set_fim_params'; the reference's own request is max_dist 14, max_angle 4.0 (cone off, :63-64). */
 int fs_score_fim(fs_ctx *ctx, int32_t n, const double *pose7, float *info_ref, float *fim21,
                  float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels);
 
