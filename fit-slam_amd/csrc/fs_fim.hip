@@ -316,14 +316,15 @@ struct Lds {
     static constexpr size_t fixed_words = (size_t)WAVES * 3 * FS_QCAP + FS_FACTOR_N;
     // One mask region per wave.  A wave culls the next candidate only after it has finished walking its own masks of
     // the current one, and no wave ever reads another wave's masks: one buffer is enough for the pipelined loop.
-    static __host__ __device__ size_t mask_words(int n_groups) { const size_t w = 2 * (size_t)WAVES * n_groups; return w + (w & 2); }
+    // (`sets` = 2 for the worker that also keeps, per chunk, whether it can meet the lookup table's box: SUMS_AT_TEST)
+    static __host__ __device__ size_t mask_words(int n_groups, int sets) { const size_t w = 2 * (size_t)WAVES * n_groups * sets; return w + (w & 2); }
     static __device__ __forceinline__ unsigned long long *masks(uint32_t *base, int n_groups)
     {
         return reinterpret_cast<unsigned long long *>(base + fixed_words);
     }
     static __device__ __forceinline__ float *factor(uint32_t *base) { return reinterpret_cast<float *>(base) + WAVES * 3 * FS_QCAP; }
     static __device__ __forceinline__ float *queue(uint32_t *base, int wave) { return reinterpret_cast<float *>(base) + wave * (3 * FS_QCAP); }
-    static __device__ __forceinline__ uint32_t *table(uint32_t *base, int n_groups) { return base + fixed_words + mask_words(n_groups); }
+    static __device__ __forceinline__ uint32_t *table(uint32_t *base, int n_groups, int sets) { return base + fixed_words + mask_words(n_groups, sets); }
 };
 
 // The work of one persistent workgroup: items [0, count) of a list, handed out by a device-side counter.
@@ -369,7 +370,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // the wave index is uniform by construction; telling the compiler so (readfirstlane) keeps chunk ids, queue counts,
     // loop conditions and address bases in scalar registers instead of exec-masked vector code
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    __shared__ int sh_overflow[2], sh_wave_tested[2][WAVES], sh_next[2];
+    __shared__ int sh_overflow[2], sh_wave_tested[2][WAVES], sh_wave_box[2][WAVES], sh_next[2];
     __shared__ __attribute__((aligned(16))) float sh_red[WAVES * FS_NACC];
 
     const float4 *__restrict__ spheres = reinterpret_cast<const float4 *>(a.spheres);
@@ -412,7 +413,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     auto pose_word = [&](const PoseLoad &pl, int k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)pl.v, k); };
     auto pose_elem = [&](const PoseLoad &pl, int k) -> float { return __builtin_bit_cast(float, pose_word(pl, k)); };
     constexpr bool RESIDENT_SPHERES = !GLOBAL_TABLE;              // (the 1024-thread HBM tier has no registers to spare)
-    constexpr int N_RES = 4;                                      // passes whose spheres stay in registers
+    // passes whose spheres stay in registers (three where the cull also keeps the box masks: the fourth sphere's registers are
+    // what that worker needs to stay within 128 without spilling, and one sphere load per 60-us candidate is nothing)
+    constexpr int N_RES = SUMS_AT_TEST ? 3 : 4;
     float4 sp_res[N_RES];
 #pragma unroll
     for (int u = 0; u < N_RES; ++u) {
@@ -423,6 +426,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     }
     auto cull = [&](const PoseLoad &pl, int buf, float *Rn, float *tn) {
         unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
+        unsigned long long *bmasks = masks + WAVES * a.n_groups;    // SUMS_AT_TEST: the accepted chunks that can meet the table's box
         const bool dead = (int)pose_word(pl, 12) != FS_STATUS_OK;
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rn[i] = pose_elem(pl, i);
@@ -430,7 +434,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         for (int i = 0; i < 3; ++i) tn[i] = pose_elem(pl, 9 + i);
         const float ax = Rn[0], ay = Rn[3], az = Rn[6];             // the camera's +x axis in the world frame (R[0], R[3], R[6])
         const float t0 = tn[0], t1 = tn[1], t2 = tn[2];
-        int tested = 0;
+        int tested = 0, tested_box = 0;
         // One sphere against the visibility volume, conservatively (s.w carries a safety margin), as the sign of ONE value: every
         // condition is "a difference is >= 0" (exact in floating point), AND is a minimum, OR a maximum — straight-line code, no
         // exec-mask nesting (three levels of it and their scalar bookkeeping in the branchy version).  A lane without a chunk
@@ -438,23 +442,27 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         // (returned as the float whose sign decides, so that the ballot is the mask of ONE compare — a boolean merged from the
         // two branches is materialised with a select and a second compare, and ANDing a "candidate is alive" mask on top costs
         // three scalar instructions per pass: a dead candidate writes empty masks instead)
+        // the sphere's centre in the camera frame against the lookup table's box grown by the radius (a superset of "the sphere
+        // meets the box"; the box is half a voxel wider than the outermost lattice points plus a millimetre): >= 0 iff it can.
+        // What INFO_ONLY culls with — and what SUMS_AT_TEST keeps as a second mask: its later scoring passes only hash, and only
+        // what is in the box can be hashed.
+        auto box_one = [&](const float4 s) -> float {
+            const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;
+            const float cx = dx * Rn[0] + dy * Rn[3] + (YAW_ONLY ? 0.0f : dz * Rn[6]);
+            const float cy = dx * Rn[1] + dy * Rn[4] + (YAW_ONLY ? 0.0f : dz * Rn[7]);
+            const float cz = YAW_ONLY ? dz : dx * Rn[2] + dy * Rn[5] + dz * Rn[8];
+            const float bx = fminf((cx + s.w) - a.box_lo[0], a.box_hi[0] - (cx - s.w));
+            const float by = fminf((cy + s.w) - a.box_lo[1], a.box_hi[1] - (cy - s.w));
+            const float bz = fminf((cz + s.w) - a.box_lo[2], a.box_hi[2] - (cz - s.w));
+            return fminf(bx, fminf(by, bz));
+        };
         auto cull_one = [&](int j, const float4 s) -> float {
             if (!a.cull) return j < a.n_chunks ? 0.0f : -1.0f;        // brute force (wave-uniform)
             const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;
             const float d2 = dx * dx + dy * dy + dz * dz;
             const float reach = a.max_dist_f + s.w, r2 = s.w * s.w;
             float c = fminf(reach, reach * reach - d2);               // within reach of the range sphere
-            if (INFO_ONLY) {
-                // the sphere's centre in the camera frame against the table box grown by the radius (a superset of "the sphere
-                // meets the box"); the box is half a voxel wider than the outermost lattice points plus a millimetre
-                const float cx = dx * Rn[0] + dy * Rn[3] + (YAW_ONLY ? 0.0f : dz * Rn[6]);
-                const float cy = dx * Rn[1] + dy * Rn[4] + (YAW_ONLY ? 0.0f : dz * Rn[7]);
-                const float cz = YAW_ONLY ? dz : dx * Rn[2] + dy * Rn[5] + dz * Rn[8];
-                const float bx = fminf((cx + s.w) - a.box_lo[0], a.box_hi[0] - (cx - s.w));
-                const float by = fminf((cy + s.w) - a.box_lo[1], a.box_hi[1] - (cy - s.w));
-                const float bz = fminf((cz + s.w) - a.box_lo[2], a.box_hi[2] - (cz - s.w));
-                c = fminf(c, fminf(bx, fminf(by, bz)));
-            }
+            if (INFO_ONLY) c = fminf(c, box_one(s));
             if (CONE == FS_CONE_NARROW || (CONE == FS_CONE_ANY && a.cone_mode == 1)) {
                 // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
                 // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one hardware
@@ -469,7 +477,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (dead) {
             if (lane == 0) {
                 for (int g = 0; g < a.n_groups; ++g) masks[g] = 0ull;
+                if (SUMS_AT_TEST) for (int g = 0; g < a.n_groups; ++g) bmasks[g] = 0ull;
                 sh_wave_tested[buf][wave] = 0;
+                if (SUMS_AT_TEST) sh_wave_box[buf][wave] = 0;
             }
             return;
         }
@@ -492,10 +502,19 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(c >= 0.0f);
                     tested += __popcll(mask);
                     if (lane == 0) masks[gb + u] = mask;
+                    if (SUMS_AT_TEST) {
+                        // (a chunk outside the range sphere is outside both masks: the box value only matters where c >= 0)
+                        float cb = a.cull ? box_one(sp[u]) : 0.0f;
+                        asm volatile("" : "+v"(cb));
+                        const unsigned long long bmask = __builtin_amdgcn_ballot_w64(cb >= 0.0f) & mask;
+                        tested_box += __popcll(bmask);
+                        if (lane == 0) bmasks[gb + u] = bmask;
+                    }
                 }
             }
         }
         if (lane == 0) sh_wave_tested[buf][wave] = tested;         // chunks this wave will scan
+        if (SUMS_AT_TEST && lane == 0) sh_wave_box[buf][wave] = tested_box;   // ... and can hash from
     };
 
     // Pass prediction: distinct voxels <= skip32/32 of the landmarks scanned.  FsFimArgs::skip32 (13/32: p99 0.40 on C3) is the
@@ -561,10 +580,17 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         unsigned long long t_cand;
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_cand) :: "memory");
 #endif
-        int wg_tested = 0;
+        int wg_tested = 0, wg_box = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) wg_tested += sh_wave_tested[buf][w];
+        if (SUMS_AT_TEST) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) wg_box += sh_wave_box[buf][w];
+        }
         wg_tested = __builtin_amdgcn_readfirstlane(wg_tested);
+        // what the hash table sees: every accepted chunk — or, SUMS_AT_TEST, only those that can meet the table's box (the pass
+        // prediction, the table size and the learnt voxel ratio are all relative to this number; later passes scan only these)
+        const int wg_hash = SUMS_AT_TEST ? __builtin_amdgcn_readfirstlane(wg_box) : wg_tested;
 
         // ---- size and clear the hash table.  Distinct voxels are at most ~0.5 of the landmarks scanned (measured
         // p99 0.40, max 0.50): a table with as many slots as landmarks scanned stays below half full, so small
@@ -584,7 +610,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         bool skip_tier = false;
         if (!GLOBAL_TABLE) {
             // = landmarks scanned * skip32 / 32, in 32 bits (beyond 2^20 accepted chunks the answer is the HBM tier anyway)
-            const uint32_t scanned2 = (uint32_t)(wg_tested < (1 << 20) ? wg_tested : (1 << 20)) * 2u;
+            const uint32_t scanned2 = (uint32_t)(wg_hash < (1 << 20) ? wg_hash : (1 << 20)) * 2u;
             const uint32_t predicted = scanned2 * (uint32_t)skip32_eff;
             const int k = (predicted > capacity ? 1 : 0) + (predicted > 2u * capacity ? 1 : 0) + (predicted > 4u * capacity ? 1 : 0) +
                           (predicted > 8u * capacity ? 1 : 0);
@@ -594,7 +620,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         int bits = tier_bits;
         if (!GLOBAL_TABLE && n_parts == 1) {
             // smallest table with at least as many slots as landmarks scanned, between 2^10 and the tier's size
-            const uint32_t want = (uint32_t)wg_tested * 64u;     // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
+            const uint32_t want = (uint32_t)wg_hash * 64u;       // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
             const int need = want > 1024u ? 32 - __builtin_clz(want - 1u) : 10;
             bits = need < tier_bits ? need : tier_bits;
         }
@@ -646,6 +672,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         const unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
 
         for (int part = 0; part < n_parts && !skip_tier; ++part) {
+        // (SUMS_AT_TEST: the first pass tests every accepted chunk — sums and count —, the later ones only hash)
+        if (SUMS_AT_TEST && part == 1) masks += WAVES * a.n_groups;
         if (part > 0) {
             // next pass: everybody is done with the table -> clear it
             __syncthreads();
@@ -828,12 +856,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         }
         if (tid == 0) {
             // tier that must re-score the candidate (0: done) | chunks scanned per pass << 4 (the finish kernel's voxel ratio)
-            a.overflow[c] = (failed ? fail_code : 0u) | ((uint32_t)(wg_tested < (1 << 27) ? wg_tested : (1 << 27)) << 4);
-            if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);   // landmarks tested (M_tested), summed by the finish kernel
+            a.overflow[c] = (failed ? fail_code : 0u) | ((uint32_t)(wg_hash < (1 << 27) ? wg_hash : (1 << 27)) << 4);
+            const uint32_t lm_tested = SUMS_AT_TEST ? (uint32_t)wg_tested * 64u + (uint32_t)wg_hash * 64u * (uint32_t)(n_parts - 1)   // first pass + the later ones
+                                                    : (uint32_t)wg_tested * 64u * (uint32_t)n_parts;
+            if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], lm_tested);   // landmarks tested (M_tested), summed by the finish kernel
             // what this candidate cost, filed under its block of the map for the order of the next call (fs_sort.hip)
             // (the key was requested with the pose record: a load here would hold thread 0 — and with it the workgroup's next
             // barrier — for a memory round trip)
-            if (!GLOBAL_TABLE && a.costmap) atomicMax(&a.costmap[cur_key & (FS_COST_BINS - 1)], (uint32_t)wg_tested * 64u * (uint32_t)n_parts);
+            if (!GLOBAL_TABLE && a.costmap) atomicMax(&a.costmap[cur_key & (FS_COST_BINS - 1)], lm_tested);
             if (!GLOBAL_TABLE && n_parts > 1 && !failed) atomicAdd(&a.counters[1], 1ull);   // scored in several passes
             if (failed && !GLOBAL_TABLE) {
                 const unsigned long long slot = atomicAdd(&a.counters[2], 1ull);
@@ -875,7 +905,8 @@ void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
-    fim_worker<THREADS, false, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups), a.hash_bits);
+    constexpr int MASK_SETS = (CONE == FS_CONE_OFF && !INFO_ONLY) ? 2 : 1;      // (= SUMS_AT_TEST of the worker)
+    fim_worker<THREADS, false, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups, MASK_SETS), a.hash_bits);
 }
 
 // HBM tier: candidates the LDS tier appended to its work list; table in HBM with 2x the landmark count of slots and
@@ -1009,11 +1040,11 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
 }
 
 template <int THREADS>
-size_t lds_bytes(int hash_bits, bool global_table, int n_chunks, int *n_groups)
+size_t lds_bytes(int hash_bits, bool global_table, int n_chunks, int *n_groups, int mask_sets)
 {
     constexpr int WAVES = THREADS / 64;
     *n_groups = (n_chunks + WAVES * 64 - 1) / (WAVES * 64);
-    const size_t mask_words = Lds<THREADS>::mask_words(*n_groups);   // table stays 16-byte aligned
+    const size_t mask_words = Lds<THREADS>::mask_words(*n_groups, mask_sets);   // table stays 16-byte aligned
     return sizeof(uint32_t) * (Lds<THREADS>::fixed_words + mask_words + (global_table ? 0 : ((size_t)1 << hash_bits)));
 }
 
@@ -1042,7 +1073,7 @@ namespace {
 template <bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY>
 hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
 {
-    const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups);
+    const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups, (CONE == FS_CONE_OFF && !INFO_ONLY) ? 2 : 1);
     auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY>;
     hipError_t e = allow_lds(kernel, lds);
     if (e != hipSuccess) return e;
@@ -1057,7 +1088,7 @@ template <bool TABLE_FULL>
 hipError_t launch_overflow(FsFimArgs &a, int pool, hipStream_t s)
 {
     const int blocks = a.n < pool ? a.n : pool;
-    const size_t lds3 = lds_bytes<FS_HBM_THREADS>(0, true, a.n_chunks, &a.n_groups);
+    const size_t lds3 = lds_bytes<FS_HBM_THREADS>(0, true, a.n_chunks, &a.n_groups, 1);
     auto kernel3 = fs_fim_tier3_kernel<FS_HBM_THREADS, TABLE_FULL>;
     hipError_t e = allow_lds(kernel3, lds3);
     if (e != hipSuccess) return e;
@@ -1074,16 +1105,18 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
     const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
     // The specialised workers exist for finite tables (every generated one) and the two common cone modes; anything else runs the
     // general worker, which computes a superset (the finish kernel then hands out what was asked for).
+    // (the cone-off workers size their passes by the chunks that can meet the table's box — SUMS_AT_TEST, INFO_ONLY —, and a pose
+    // shows more distinct voxels per landmark of THOSE than of everything in range: the cap of the pass prediction follows)
+    if (cone == FS_CONE_OFF && a.skip32 < 20) a.skip32 = 20;
     const bool special = a.table_full && cone != FS_CONE_ANY;
     if (!special || (!a.info_only && !a.yaw_only)) {
         if (cone == FS_CONE_OFF) return a.table_full ? launch_tier1<true, FS_CONE_OFF, false, false>(a, s) : launch_tier1<false, FS_CONE_OFF, false, false>(a, s);
         if (cone == FS_CONE_NARROW) return a.table_full ? launch_tier1<true, FS_CONE_NARROW, false, false>(a, s) : launch_tier1<false, FS_CONE_NARROW, false, false>(a, s);
         return a.table_full ? launch_tier1<true, FS_CONE_ANY, false, false>(a, s) : launch_tier1<false, FS_CONE_ANY, false, false>(a, s);
     }
-    if (a.info_only) {
-        if (a.yaw_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, true>(a, s);
-        return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false>(a, s);
-    }
+    // (info_only comes from fs_score_fim, whose poses are general; the fused path — the one with yaw-only poses — always wants
+    // the full records: the two flags never meet, and no INFO_ONLY x YAW_ONLY worker is instantiated)
+    if (a.info_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false>(a, s);
     return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, true>(a, s);
 }
 
