@@ -156,7 +156,10 @@ def _build_locked(force: bool, verbose: bool) -> str:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
             res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
             usage = _parse_resource_remarks(res.stderr)
-            rest = "\n".join(l for l in res.stderr.splitlines() if "kernel-resource-usage" not in l and l.strip())
+            import re as _re
+            # (the remarks come with source-context lines — "  160 | {", "      | ^" — that are noise without them)
+            rest = "\n".join(l for l in res.stderr.splitlines()
+                             if "kernel-resource-usage" not in l and l.strip() and not _re.match(r"^\s*\d*\s*\|", l))
             if rest:
                 print(rest, file=sys.stderr, flush=True)       # (never stdout: bench.py's one JSON line lives there)
             if res.returncode != 0:
