@@ -293,6 +293,23 @@ def run_latency(args) -> int:
             cpu_us = (time.perf_counter() - t0) * 1e6
             ok = bool(np.array_equal(rec["arrival"], arr["arrival"]) and np.array_equal(rec["n_visible"][arr["status"] == 0], fim["n_visible"][arr["status"] == 0]))
             res["score_candidates"][str(n)] = dict(_percentiles(ts), cpu_oracle_1thread_us=cpu_us, parity_integers=ok)
+        # the whole cost assignment of a tick as ONE call (fs_get_frontier_costs: arrival information + U1 + order; what the
+        # reference's assignCosts computes), path columns as the Euclidean stand-in planner would set them
+        res["get_frontier_costs"] = {}
+        for n in (50, 200, 2000):
+            g, f, b = w.goals[:n], w.frontier_size[:n], w.blacklisted[:n]
+            pl = np.hypot(g[:, 0], g[:, 1]) + 0.5
+            ph = np.abs(np.arctan2(g[:, 1], g[:, 0]))
+            sc.set_arrival_limits(max(mx["max_gt"], 1000.0) * 4, mx["min_gt"])      # (C1's 3.2 m map cannot hold the calibration fan: limits by hand)
+            for _ in range(20):
+                sc.get_frontier_costs(g, pl, ph, f, b, with_fim=False)
+            ts = []
+            for _ in range(args.latency_calls):
+                t0 = time.perf_counter()
+                fc = sc.get_frontier_costs(g, pl, ph, f, b, with_fim=False)
+                ts.append((time.perf_counter() - t0) * 1e6)
+            sc.set_arrival_limits(mx["max_gt"], mx["min_gt"])
+            res["get_frontier_costs"][str(n)] = dict(_percentiles(ts), order_is_a_permutation=bool(np.array_equal(np.sort(fc["order"]), np.arange(n))))
         # isPoseSafe: ONE pose (the pose of candidate 0 at its best yaw)
         pose = O.poses_from_yaw(w.goals[:1], np.array([float(rec_all["yaw"][0])]))
         for _ in range(20):

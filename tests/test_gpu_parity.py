@@ -640,3 +640,24 @@ def test_fim_table_with_holes(fs, oracle, scorer, ref_table):
         assert np.max(np.abs(rec_gpu["info_ref"][ok] - fim["info_f64"][ok]) / sc) <= REL
     finally:
         scorer.lookup_generate()
+
+
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 1023, 1024, 1025, 5000, 32768, 32769, 70000])
+def test_rank_order_is_the_stable_ascending_sort_at_every_size(fs, oracle, scorer, n):
+    """Up to 32 768 candidates the order comes from ONE all-pairs counting kernel (fs_rank_order_kernel), beyond from rocPRIM's
+    sort: both must be numpy's stable argsort of the (bit-exact) costs — with thousands of equal costs (the unachievable and
+    blacklisted candidates all carry DBL_MAX, and quantised path lengths make ties among the live ones)."""
+    rng = np.random.default_rng(n)
+    rec = np.zeros(n, dtype=fs.capi.RECORD_DTYPE)
+    rec["arrival"] = rng.integers(0, 400, size=n)
+    ach = rng.random(n) < 0.7
+    rec["flags"] = ach.astype(np.uint32)
+    black = (rng.random(n) < 0.05).astype(np.uint8)
+    plen = np.round(rng.uniform(0.5, 30.0, size=n), 0)               # whole metres: many exact ties
+    phead = np.round(rng.uniform(0.0, 3.0, size=n), 1)
+    scorer.set_arrival_limits(400.0, 40.0)
+    rc, want = oracle.u1_costs(rec["arrival"].astype(np.float64), ach.astype(np.uint8), plen, phead, 400.0, blacklisted=black)
+    assert rc == 0
+    got = scorer.rank_candidates(rec, plen, phead, blacklisted=black)
+    np.testing.assert_array_equal(got["weighted_cost"], want["weighted_cost"])
+    np.testing.assert_array_equal(got["order"], np.argsort(want["weighted_cost"], kind="stable"))
