@@ -84,3 +84,20 @@ def test_shard_bounds_cover_and_order():
                 assert 0 <= hi - lo <= cap and (lo == min(n, r * cap))
                 if r:
                     assert lo == spans[r - 1][1]
+
+
+def test_weak_scaling_blocks_are_functions_of_config_and_rank(fs):
+    """bench.py's weak scaling: every rank builds the same map and cloud and ONLY its own block of the n x world list
+    (synth.candidate_block).  Block 0 is the N = 1 list itself; block r is the same on whichever rank computes it (rank 0 rebuilds
+    the sampled blocks for the parity gate) and differs from the others; all of them are frontier cells of the same grid."""
+    w = fs.synth.make_workload("C1")
+    g0, f0, b0 = fs.synth.candidate_block(w, "C1", 0)
+    assert g0 is w.goals and f0 is w.frontier_size and b0 is w.blacklisted
+    g1a, f1a, b1a = fs.synth.candidate_block(w, "C1", 1)
+    g1b, f1b, b1b = fs.synth.candidate_block(fs.synth.make_workload("C1"), "C1", 1)
+    np.testing.assert_array_equal(g1a, g1b); np.testing.assert_array_equal(f1a, f1b); np.testing.assert_array_equal(b1a, b1b)
+    g2, _, _ = fs.synth.candidate_block(w, "C1", 2)
+    assert g1a.shape == w.goals.shape == g2.shape and not np.array_equal(g1a, g2) and not np.array_equal(g1a, w.goals)
+    # frontier cells: free cells (cost 0) of the grid, at cell centres
+    cell = np.floor((g1a - np.asarray(w.origin)) / w.resolution).astype(int)
+    assert np.all(w.cells[cell[:, 2], cell[:, 1], cell[:, 0]] == 0)
