@@ -1522,14 +1522,6 @@ static int run_fim_rest(fs_ctx *c, FsFimArgs &a)
     return FS_OK;
 }
 
-static int run_fim(fs_ctx *c, FsFimArgs &a)
-{
-    bind_fim_outputs(c, a);
-    int rc = run_fim_tier1(c, a, nullptr, 0, a.n);
-    if (rc) return rc;
-    return run_fim_rest(c, a);
-}
-
 int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, float *fim21,
                  float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels)
 {
