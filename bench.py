@@ -133,7 +133,7 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def counter_profile(workload: str, depth_cells: int):
+def counter_profile(workload: str, depth_cells: int, fim_angle: float = 1.0):
     """PMC-derived figures (profiles/pmc_summary.json, written by tools/pmc_collect.py on the GPU box) — used ONLY when
     the file was measured on exactly these kernel sources and this workload; otherwise the line says unmeasured."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -142,6 +142,8 @@ def counter_profile(workload: str, depth_cells: int):
     except Exception:
         return None
     if j.get("source_hash") != source_hash() or j.get("workload") != workload or int(j.get("depth_cells", 0)) != int(depth_cells):
+        return None
+    if abs(float(j.get("fim_angle", 1.0)) - float(fim_angle)) > 1e-9:      # (another visibility volume is another kernel instantiation)
         return None
     return j
 
@@ -830,7 +832,7 @@ def run_rank(args) -> int:
         launches_per_step = fim_n / max(1, n_steps_ev)
         fim_avg_s = (fim_ms / max(fim_n, 1)) * 1e-3
         achieved = (n_local * b_fim / max(launches_per_step, 1e-9)) / fim_avg_s / 1e9 if fim_n else None
-        prof = counter_profile(wl_name, args.depth_cells)
+        prof = counter_profile(wl_name, args.depth_cells, args.fim_angle)
         gpu_rec = shard.records_to_numpy(full) if not args.no_parity else None
         cpu, parity = (None, None)
         if not multi_path and args.cpu_seconds > 0:

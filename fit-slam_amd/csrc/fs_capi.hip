@@ -5,6 +5,7 @@
 #include "fs_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -23,7 +24,7 @@ hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *
 
 // Counts every (re)allocation of device / page-locked memory the library makes, in any context: a captured launch graph holds
 // raw pointers, and is only replayed while this number is what it was at capture time.
-uint64_t fs_alloc_generation = 0;
+std::atomic<uint64_t> fs_alloc_generation{0};     // (atomic: fs_multi stages its members from one host thread each)
 
 namespace {
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <vector>
 
 #include "../../include/fitslam_frontier.h"
@@ -214,7 +215,7 @@ struct FsFimArgs {
 #define FS_MAX_TABLE_CELLS ((1u << (32 - FS_SLOT_CNT_BITS)) - 2u)
 
 
-extern uint64_t fs_alloc_generation;   // bumped by every device / page-locked (re)allocation of the library (fs_capi.hip): launch graphs hold raw pointers
+extern std::atomic<uint64_t> fs_alloc_generation;   // bumped by every device / page-locked (re)allocation of the library (fs_capi.hip): launch graphs hold raw pointers
 
 // launchers (defined in the .hip files)
 hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s);

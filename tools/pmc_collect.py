@@ -141,7 +141,13 @@ def main():
     if args.depth_cells:
         bench += ["--depth-cells", str(args.depth_cells)]
     bench += args.bench_arg
-    summary = {"source_hash": source_hash(), "workload": args.workload, "depth_cells": args.depth_cells,
+    fim_angle = 1.0
+    for i, arg in enumerate(args.bench_arg):
+        if arg == "--fim-angle" and i + 1 < len(args.bench_arg):
+            fim_angle = float(args.bench_arg[i + 1])
+        elif arg.startswith("--fim-angle="):
+            fim_angle = float(arg.split("=", 1)[1])
+    summary = {"source_hash": source_hash(), "workload": args.workload, "depth_cells": args.depth_cells, "fim_angle": fim_angle,
                "collected_with": "tools/pmc_collect.py: rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- "
                                  "python3 bench.py --steps 3 --warmup 2 --repeats 2 --cpu-seconds 0 --no-parity; means over the last 6 dispatches",
                "counters_missing": []}
