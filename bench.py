@@ -136,16 +136,17 @@ def source_hash() -> str:
 def counter_profile(workload: str, depth_cells: int, fim_angle: float = 1.0):
     """PMC-derived figures (profiles/pmc_summary.json, written by tools/pmc_collect.py on the GPU box) — used ONLY when
     the file was measured on exactly these kernel sources and this workload; otherwise the line says unmeasured."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    try:
-        j = json.load(open(path))
-    except Exception:
-        return None
-    if j.get("source_hash") != source_hash() or j.get("workload") != workload or int(j.get("depth_cells", 0)) != int(depth_cells):
-        return None
-    if abs(float(j.get("fim_angle", 1.0)) - float(fim_angle)) > 1e-9:      # (another visibility volume is another kernel instantiation)
-        return None
-    return j
+    for name in ("pmc_summary.json", "pmc_summary_ref_request.json"):      # (the headline's, and the one collected at --fim-angle 4.0)
+        try:
+            j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if j.get("source_hash") != source_hash() or j.get("workload") != workload or int(j.get("depth_cells", 0)) != int(depth_cells):
+            continue
+        if abs(float(j.get("fim_angle", 1.0)) - float(fim_angle)) > 1e-9:  # (another visibility volume is another kernel instantiation)
+            continue
+        return j
+    return None
 
 
 def cpu_model() -> str:

@@ -18,4 +18,4 @@ run latency_reference_request python3 bench.py --latency --latency-calls 500 --f
 run gloo2_rehearsal_bench python3 bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --repeats 3
 ( cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/stats_default -- $PY $GRAFT_REPO_ROOT/bench.py --steps 20 --cpu-seconds 0 > $GRAFT_REPO_ROOT/$O/stats_default.log 2>&1; echo "stats rc=$?" )
 cp $(find $O/stats_default -name "*kernel_stats.csv" | head -1) $O/c3_all_workers_kernel_stats.csv 2>/dev/null
-timeout -k 10 500 python3 tools/pmc_collect.py --out gpurun_out/pmc_r04_ref --skip-calib --passes insts,cycles,stalls,grbm,fetch,write,tcc --bench-arg=--fim-angle --bench-arg=4.0 > $O/pmc_ref.log 2>&1; echo "pmc_ref rc=$?"
+timeout -k 10 500 python3 tools/pmc_collect.py --out gpurun_out/pmc_r04_ref --passes insts,cycles,stalls,grbm,fetch,write,tcc --bench-arg=--fim-angle --bench-arg=4.0 > $O/pmc_ref.log 2>&1; echo "pmc_ref rc=$?"
