@@ -67,3 +67,16 @@ def test_source_hash_tracks_the_kernel_sources():
     assert len(h) == 16 and h == b.source_hash()
     # a counter profile is only replayed into the bench line when it names exactly these sources
     assert b.counter_profile("no-such-workload", 0) is None
+
+
+def test_counter_profiles_are_replayed_only_for_what_they_measured():
+    """bench.py copies counter-derived figures (HBM traffic, what limits the kernel) into its line only from a profile that was
+    collected on exactly these kernel sources, this workload AND this visibility volume — the cone-off request runs another FIM
+    worker instantiation, with counters of its own (profiles/pmc_summary_ref_request.json)."""
+    b = _bench_module()
+    for name, angle in (("pmc_summary.json", 1.0), ("pmc_summary_ref_request.json", 4.0)):
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert float(j.get("fim_angle", 1.0)) == angle and j["workload"] == "C3"
+        if j["source_hash"] == b.source_hash():                      # (a committed profile of older sources is simply not replayed)
+            assert b.counter_profile("C3", 0, angle)["fim_angle"] == angle
+    assert b.counter_profile("C3", 0, 2.5) is None and b.counter_profile("C5", 0, 1.0) is None and b.counter_profile("C3", 160, 1.0) is None
