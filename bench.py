@@ -57,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
+    ap.add_argument("--min-timed-seconds", type=float, default=0.5, help="keep adding timed blocks of --steps steps (beyond --repeats) until the timed GPU work adds up to this much: 5 blocks of 20 C3 steps are only 79 ms, too thin for a median (0 = exactly --repeats blocks)")
     ap.add_argument("--pipeline", type=int, default=1, help="scorer contexts (HIP streams) per GPU; successive batches alternate over them (1, the default = one stream, batches strictly back to back; 2 measured +2 %% on C3, but the two FIM kernels then share the CUs and their per-launch durations no longer measure the kernel)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--workload", default="C3", help="C3 (headline) | C5 | REF2D (the reference's own 2-D operating point: 63 rays, L = 40) | C2 | C1")
@@ -64,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--fim-angle", type=float, default=1.0, help="visibility cone half-angle in rad for the timed steps (1.0: the build's definition, SURVEY.md App. A.3; 4.0 = the reference's own request, FisherInfoManager.cpp:63-64: cone off).  The N = 1 line always carries the other one under other_operating_points.reference_request_visibility")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time (three runs, median); 0 disables")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling block (160 k candidates split over the ranks) that follows the weak blocks")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI; the measured configuration) | gloo (rehearsal of the N > 1 path on one GPU: ranks share the device, records are gathered through host memory)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE", help="fs_set_option knobs, e.g. ray.layout=2")
     ap.add_argument("--latency", action="store_true", help="the drop-in operating point instead of the throughput line: p50 / p99 of ONE fs_score_candidates call (host buffers in, records out, synchronised) at 1 / 50 / 200 / 2000 frontiers on REF2D and C1, of fs_score_fim(n = 1) and of fs_frontier_clusters on a 512^2 costmap, each with the oracle's single-thread time beside it")
@@ -149,6 +151,39 @@ def counter_profile(workload: str, depth_cells: int, fim_angle: float = 1.0):
     return None
 
 
+def host_cpu_topology() -> dict:
+    """What 'all host cores' means on this box: logical CPUs this process may run on, physical cores among them (distinct
+    (package, core id) pairs of /proc/cpuinfo), SMT state, and the cgroup's CPU quota if there is one."""
+    usable = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    cores, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in usable:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in usable:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except (OSError, ValueError):
+        pass
+    smt = None
+    try:
+        smt = open("/sys/devices/system/cpu/smt/active").read().strip() == "1"
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return {"logical_cpus_usable": len(usable), "physical_cores_usable": len(cores) or None, "smt_active": smt,
+            "cgroup_cpu_quota_cores": quota}
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -168,20 +203,31 @@ def compare_records(r, arr, fim, fim_angle):
             np.array_equal(r["flags"] & 1, arr["achievable"]) and
             np.array_equal(r["n_visible"][ok], fim["n_visible"][ok]) and
             np.array_equal(((r["flags"] >> 16) & 0xFFFF)[ok], np.minimum(fim["n_voxels"][ok], 65535)))
-    sc = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
-    e_info = float(np.max(np.abs(r["info_ref"][ok] - fim["info_f64"][ok]) / sc)) if ok.any() else 0.0
-    e_tr = float(np.max(np.abs(r["trace"][ok] - fim["trace"][ok]) / np.maximum(fim["trace"][ok], 1e-6))) if ok.any() else 0.0
-    # D-optimality: no reference counterpart (the reference keeps the trace only) — against the float64 oracle, relative to
-    # max(1, |log det|), over the candidates where both are finite; the share within north_star's 1e-4 is reported
-    fin = ok & np.isfinite(fim["logdet"]) & np.isfinite(r["logdet"])
-    e_ld = np.abs(r["logdet"][fin] - fim["logdet"][fin]) / np.maximum(1.0, np.abs(fim["logdet"][fin]))
-    same_sing = bool(np.array_equal(np.isfinite(r["logdet"][ok]), np.isfinite(fim["logdet"][ok])))
-    return {"n": n_s, "integers_bit_exact": bool(ints), "info_max_rel_err": e_info, "trace_max_rel_err": e_tr,
-            "logdet_max_rel_err": float(e_ld.max()) if e_ld.size else 0.0,
-            "logdet_share_within_1e-4": float(np.mean(e_ld <= 1e-4)) if e_ld.size else 1.0,
-            "logdet_finite_candidates": int(fin.sum()), "logdet_singularity_agrees": same_sing,
-            "visibility": f"14 m, {fim_angle} rad",
-            "ok": bool(ints and e_info <= 1e-4 and e_tr <= 1e-4 and (e_ld.size == 0 or e_ld.max() <= 1e-4))}
+    parity = importlib.import_module("fit-slam_amd.parity")      # the ONE tolerance rule (tests use the same functions)
+    e_info = parity.rel_err(r["info_ref"][ok], fim["info_f64"][ok])
+    e_tr = parity.rel_err(r["trace"][ok], fim["trace"][ok])
+    # D-optimality: no reference counterpart (the reference keeps the trace only) — against the float64 oracle under
+    # fit-slam_amd/parity.py's rule: plain 1e-4 of max(1, |log det|) plus kappa(F) * 2^-24, the rounding of a float32 F's
+    # entries (only poses with three or four visible landmarks, kappa >= 1e5, need the second term: profiles/r05/logdet_probe_*.json).
+    # The share within PLAIN 1e-4 is reported next to the share within the rule.
+    gate = parity.logdet_gate(r["logdet"], fim["logdet"], fim["fim"], consider=ok, n_visible=fim["n_visible"])
+    out = {"n": n_s, "integers_bit_exact": bool(ints), "info_max_rel_err": e_info, "trace_max_rel_err": e_tr}
+    out.update({k: v for k, v in gate.items() if k != "ok"})
+    out["visibility"] = f"14 m, {fim_angle} rad"
+    out["ok"] = bool(ints and e_info <= parity.REL and e_tr <= parity.REL and gate["ok"])
+    return out
+
+
+def red_gates(obj, path="") -> list:
+    """Every `parity`-like block of the result line whose `ok` is false (paths into the line)."""
+    red = []
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            here = f"{path}.{k}" if path else k
+            if isinstance(v, dict) and "parity" in k and v.get("ok") is False:
+                red.append(here)
+            red += red_gates(v, here)
+    return red
 
 
 def sample_parity(w, arrival_kw, mx, goals, fsize, black, rec, fim_angle, where):
@@ -233,11 +279,24 @@ def cpu_baseline(w, arrival_kw, n_total, target_s, gpu_rec, mx, fim_angle=1.0):
            "runs_s": times, "min_run_value": n_s / max(times), "max_run_value": n_s / min(times)}
     dt_c, _, _ = run(0, n_s, 1, False)
     out["clean_value"] = n_s / dt_c          # BASELINE.md `cpu_clean`: same results, no per-ray vectors / O(k^2) dedupe, one thread
-    cores = min(16, os.cpu_count() or 1)     # the GPU box's CPU share for one GPU
+    topo = host_cpu_topology()
+    out["host"] = topo
+    cores = min(16, topo["logical_cpus_usable"])     # the GPU box's CPU share for one GPU
     n_o = min(n_total, n_s * min(cores, 16))
     dt_o, _, _ = run(0, n_o, cores, False)
     out["omp_value"] = n_o / dt_o
     out["omp_cores"] = cores
+    # OpenMP over candidates on ALL host cores of the box — every logical CPU this process may run on,
+    # and (SMT on) one thread per physical core beside it; the whole list when the sample would be too short to fill them.
+    # Best of two runs each (the first one also pays the threads' creation).
+    for key, thr in (("omp_all", topo["logical_cpus_usable"]), ("omp_physical", topo["physical_cores_usable"])):
+        if not thr or (key == "omp_physical" and thr == topo["logical_cpus_usable"]):
+            continue
+        n_a = min(n_total, max(n_o, n_s * thr, 64 * thr))
+        dt_a = min(run(0, n_a, thr, False)[0] for _ in range(2))
+        out[key + "_value"] = n_a / dt_a
+        out[key + "_cores"] = thr
+        out[key + "_sample"] = f"first {n_a} of {n_total} candidates, {thr} OpenMP threads (schedule dynamic), best of 2 runs of {dt_a:.2f} s"
     parity = compare_records(gpu_rec[:n_s], arr, fim, fim_angle) if gpu_rec is not None else None
     return out, parity
 
@@ -314,7 +373,7 @@ def run_latency(args) -> int:
             sc.set_arrival_limits(mx["max_gt"], mx["min_gt"])
             res["get_frontier_costs"][str(n)] = dict(_percentiles(ts), order_is_a_permutation=bool(np.array_equal(np.sort(fc["order"]), np.arange(n))))
         # isPoseSafe: ONE pose (the pose of candidate 0 at its best yaw)
-        pose = O.poses_from_yaw(w.goals[:1], np.array([float(rec_all["yaw"][0])]))
+        pose = fs.synth.poses_from_yaw(w.goals[:1], np.array([float(rec_all["yaw"][0])]))
         for _ in range(20):
             sc.score_fim(pose, want_fim=False)
         ts = []
@@ -367,6 +426,7 @@ def other_visibility(args, sc, w, n_local, d_goal, d_fsize, d_black, d_rec, dev,
     over the step's poses that asks for info_ref alone (the INFO_ONLY worker: what isPoseSafe reads), both with their kernel
     time, landmarks tested per candidate, pass and HBM-tier counts, and gated against the oracle on a sample."""
     import torch
+    fs = importlib.import_module("fit-slam_amd")
     shard = importlib.import_module("fit-slam_amd.shard")
     angle = 4.0 if args.fim_angle < np.pi else 1.0
     sc.set_fim_params(14.0, angle)
@@ -406,10 +466,10 @@ def other_visibility(args, sc, w, n_local, d_goal, d_fsize, d_black, d_rec, dev,
         rec = shard.records_to_numpy(d_rec[:n_local])
         # the step's poses through fs_score_fim, info_ref alone (host poses in, two columns out: PCIe included in ms_per_call)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as O   # pose construction for the call + the checker of the sample below
+        import oracle as O   # the checker of the sample below
         # (the pose of a candidate: goal + the yaw of its best window in DOUBLE, argmax * delta_theta + fov / 2 as
         # CostCalculator.cpp:119 — the record's float32 yaw would turn the camera by 1e-7 rad and move landmarks across voxel faces)
-        poses = O.poses_from_yaw(w.goals[:n_local], rec["argmax"].astype(np.float64) * w.delta_theta + w.camera_fov / 2)
+        poses = fs.synth.poses_from_yaw(w.goals[:n_local], rec["argmax"].astype(np.float64) * w.delta_theta + w.camera_fov / 2)
         for _ in range(2):
             r_info = sc.score_fim(poses, info_only=True)
         sc.get_counter(0, reset=True)
@@ -449,6 +509,9 @@ def other_visibility(args, sc, w, n_local, d_goal, d_fsize, d_black, d_rec, dev,
             p = out["parity"]
             p["ok"] = bool(p["fused_n_visible_bit_exact"] and p["fused_n_voxels_bit_exact"] and p["info_only_n_voxels_bit_exact"]
                            and p["fused_info_max_rel_err"] <= 1e-4 and p["info_only_info_max_rel_err"] <= 1e-4)
+            # the CPU path at THIS visibility volume beside it (1 thread / 16 / every host core), and the full gate — log det
+            # included — on the fused records of its sample
+            out["cpu_baseline"], out["fused_parity"] = cpu_baseline(w, arrival_kw, n_local, args.cpu_seconds * 0.5, rec, mx, angle)
     finally:
         sc.set_fim_params(14.0, args.fim_angle)
     return out
@@ -586,6 +649,8 @@ def run_rank(args) -> int:
         c.set_fim_params(14.0, args.fim_angle)
     del bricks
     mx = sc.max_arrival()
+    for c in scs[1:]:                      # (the calibration fan ran on context 0: the others rank with the same limits)
+        c.set_arrival_limits(mx["max_gt"], mx["min_gt"])
 
     # candidate columns of this rank's block, resident in HBM
     d_goal = torch.from_numpy(np.ascontiguousarray(blk_goals)).to(dev)
@@ -641,6 +706,19 @@ def run_rank(args) -> int:
     # them: the roofline's launch durations come from that block, `value` from the median block (an event-free one
     # whenever --repeats >= 3).  All blocks are listed in "timing".
     n_rep = max(1, args.repeats)
+    if args.min_timed_seconds > 0:
+        # one untimed calibration block decides the number of blocks — the SAME number on every rank (MAX over the ranks)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        cal = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if (multi_path and args.backend == "nccl") else "cpu")
+        if multi_path:
+            dist.all_reduce(cal, op=dist.ReduceOp.MAX)
+        n_rep = int(min(500, max(n_rep, np.ceil(args.min_timed_seconds / max(float(cal[0]), 1e-6)))))
+        for c in scs:
+            c.get_counter(0, reset=True)
     block_s, local_s = [], []
     full = None
     for r in range(n_rep):
@@ -743,9 +821,10 @@ def run_rank(args) -> int:
         idx = np.arange(n_total, dtype=np.float64)
         d_len = torch.from_numpy(0.5 + 29.5 * np.modf(idx * 0.6180339887498949)[0]).to(dev)
         d_head = torch.from_numpy(np.pi * np.modf(idx * 0.7548776662466927)[0]).to(dev)
-        d_cost = torch.zeros(n_total, dtype=torch.float64, device=dev)
-        d_order = torch.zeros(n_total, dtype=torch.int32, device=dev)
-        d_rerr = torch.zeros(1, dtype=torch.int32, device=dev)
+        # (one set of output columns per pipeline slot: the slots' streams are not ordered against each other)
+        d_costs = [torch.zeros(n_total, dtype=torch.float64, device=dev) for _ in range(n_pipe)]
+        d_orders = [torch.zeros(n_total, dtype=torch.int32, device=dev) for _ in range(n_pipe)]
+        d_rerrs = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(n_pipe)]
 
         def ranked_step():
             full_ = step()
@@ -755,8 +834,8 @@ def run_rank(args) -> int:
                 if pending[b] is not None:
                     pending[b].wait()                                # the ranking reads the gathered list
                     pending[b] = None
-                scs[c].rank_candidates_dev(n_total, full_.data_ptr(), d_len.data_ptr(), d_head.data_ptr(), d_cost.data_ptr(),
-                                           d_order=d_order.data_ptr(), d_err=d_rerr.data_ptr())
+                scs[c].rank_candidates_dev(n_total, full_.data_ptr(), d_len.data_ptr(), d_head.data_ptr(), d_costs[c].data_ptr(),
+                                           d_order=d_orders[c].data_ptr(), d_err=d_rerrs[c].data_ptr())
 
         for _ in range(max(2, args.warmup)):
             ranked_step()
@@ -774,11 +853,102 @@ def run_rank(args) -> int:
             c.enable_kernel_timing(False)
             for kind in range(5):
                 c.kernel_time(kind)
-        order = d_order.cpu().numpy()
-        cost = d_cost.cpu().numpy()
-        ranked = {"dt": dt_r, "rank_kernels_ms_per_step": rank_ms / max(rank_n, 1), "range_error": int(d_rerr.cpu()[0]),
-                  "order_is_a_permutation": bool(np.array_equal(np.sort(order), np.arange(n_total))),
-                  "costs_ascending": bool(np.all(np.diff(cost[order]) >= 0))}
+        checks = []
+        for c in range(n_pipe):
+            order = d_orders[c].cpu().numpy()
+            cost = d_costs[c].cpu().numpy()
+            checks.append((int(d_rerrs[c].cpu()[0]), bool(np.array_equal(np.sort(order), np.arange(n_total))), bool(np.all(np.diff(cost[order]) >= 0))))
+        ranked = {"dt": dt_r, "rank_kernels_ms_per_step": rank_ms / max(rank_n, 1), "range_error": max(x[0] for x in checks),
+                  "order_is_a_permutation": all(x[1] for x in checks), "costs_ascending": all(x[2] for x in checks)}
+
+    # ---- strong scaling beside the weak line (N > 1, and the one-rank rehearsal): SURVEY.md 8(e) "Reporting: throughput at
+    # G = 1/2/4/8 with identical total work".  configs[3]'s shape — 160 k candidates, 512^3 grid, 100 k landmarks — over the map
+    # and cloud ALREADY staged for the weak blocks (nothing is re-staged): the list is blocks 0..7 of synth.candidate_block on
+    # this workload, cut into `world` contiguous shares (fs_multi_shard_bounds' rule); a rank draws only the blocks its share
+    # touches.  Same step (score + the one all-gather), same bracketing, MAX over the ranks, median of three blocks of K steps.
+    strong = None
+    if multi_path and args.scaling == "weak" and not args.no_strong:
+        per_blk = cfg["n_cand"]
+        n_tot_s = 8 * per_blk
+        lo_s, hi_s = shard.shard_bounds(n_tot_s, world, rank)
+        cap_s = shard.shard_capacity(n_tot_s, world)
+        parts = []
+        for b in range(lo_s // per_blk, (hi_s - 1) // per_blk + 1):
+            g_, f_, k_ = fs.synth.candidate_block(w, wl_name, b)
+            a0, a1 = max(lo_s, b * per_blk) - b * per_blk, min(hi_s, (b + 1) * per_blk) - b * per_blk
+            parts.append((g_[a0:a1], f_[a0:a1], k_[a0:a1]))
+        sg = np.ascontiguousarray(np.concatenate([x[0] for x in parts]))
+        sf = np.ascontiguousarray(np.concatenate([x[1] for x in parts]))
+        sb = np.ascontiguousarray(np.concatenate([x[2] for x in parts]))
+        n_loc_s = hi_s - lo_s
+        assert sg.shape[0] == n_loc_s
+        ds_goal, ds_fsize, ds_black = torch.from_numpy(sg).to(dev), torch.from_numpy(sf).to(dev), torch.from_numpy(sb).to(dev)
+        ds_recs = [torch.zeros((cap_s, 8), dtype=torch.int32, device=dev) for _ in range(2)]
+        s_pending = [None, None]
+        s_state = {"k": 0, "full": None}
+
+        def strong_step():
+            b = s_state["k"] % 2
+            s_state["k"] += 1
+            with torch.cuda.stream(streams[0]):
+                if s_pending[b] is not None:
+                    s_pending[b].wait()
+                    s_pending[b] = None
+                sc.score_candidates_dev(n_loc_s, ds_goal.data_ptr(), ds_fsize.data_ptr(), ds_black.data_ptr(), 0, ds_recs[b].data_ptr())
+                if args.backend == "nccl":
+                    s_state["full"], s_pending[b] = shard.gather_records(ds_recs[b], n_tot_s, async_op=True)
+                else:
+                    streams[0].synchronize()
+                    s_state["full"] = shard.gather_records(ds_recs[b].cpu(), n_tot_s)
+
+        def strong_fence():
+            for b in range(2):
+                if s_pending[b] is not None:
+                    s_pending[b].wait()
+                    s_pending[b] = None
+            return fence()
+
+        for _ in range(max(2, min(args.warmup, 3))):
+            strong_step()
+        strong_fence()
+        s_block, s_local = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                strong_step()
+            t_ready = strong_fence()
+            s_block.append(time.perf_counter() - t0)
+            s_local.append(t_ready - t0)
+        red_dev = dev if args.backend == "nccl" else "cpu"
+        tm = torch.tensor(s_block, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([float(np.median(s_local))], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(x[0]) / args.steps * 1e3 for x in every]
+        dt_s = float(np.median([float(x) for x in tm.tolist()]))
+        strong = {"total_candidates": n_tot_s, "candidates_per_gpu": n_loc_s if world == 1 else cap_s, "ms_per_step": dt_s / args.steps * 1e3,
+                  "candidate_goals_per_s": n_tot_s * args.steps / dt_s, "blocks_ms_per_step": [float(x) / args.steps * 1e3 for x in tm.tolist()],
+                  "per_rank_ms_per_step": per_rank_ms, "per_rank_ms_per_step_min": min(per_rank_ms), "per_rank_ms_per_step_max": max(per_rank_ms),
+                  "workload": f"configs[3] shape on the staged {wl_name} map and cloud: 8 x {per_blk} candidates (synth.candidate_block 0..7), "
+                              f"contiguous shares of ceil(n / {world}); nothing re-staged; one all-gather of {n_tot_s} x 32 B per step",
+                  "scaling": "strong", "note": "total work identical at every N; never `value` (the weak line is). A scaling figure only when the driver has run it on N physical GPUs"}
+        # the gathered list is gated like the weak one: 48 candidates of each rank's share against the oracle (rank 0)
+        if rank == 0 and not args.no_parity:
+            rec_s = shard.records_to_numpy(s_state["full"][:n_tot_s])
+            gs, fz, bl, ix = [], [], [], []
+            blk_cache = {}
+            for r in range(world):
+                b_lo, b_hi = shard.shard_bounds(n_tot_s, world, r)
+                pick = np.unique(np.linspace(b_lo, max(b_hi - 1, b_lo), num=min(48, b_hi - b_lo)).astype(np.int64))
+                for i in pick:
+                    if int(i) // per_blk not in blk_cache:
+                        blk_cache[int(i) // per_blk] = fs.synth.candidate_block(w, wl_name, int(i) // per_blk)
+                    g_, f_, k_ = blk_cache[int(i) // per_blk]
+                    gs.append(g_[i % per_blk]); fz.append(f_[i % per_blk]); bl.append(k_[i % per_blk]); ix.append(int(i))
+            strong["parity"] = sample_parity(w, arrival_kw, mx, np.asarray(gs), np.asarray(fz, dtype=np.int32), np.asarray(bl, dtype=np.uint8),
+                                             rec_s[np.asarray(ix)], args.fim_angle, f"48 candidates evenly spaced in each of the {world} shares of the 160 k list")
+        del ds_goal, ds_fsize, ds_black, ds_recs
 
     # ---- what a sub-linear curve would be made of (N > 1): every rank's own time per step, the spread with which the ranks
     # reach the closing barrier, and the all-gather by itself (blocking calls between an event pair on the scorer's stream)
@@ -817,6 +987,7 @@ def run_rank(args) -> int:
                  "all_gather_ms": gather_ms,
                  "all_gather_note": f"one blocking all_gather_into_tensor of {n_total} x 32 B between an event pair on the scorer's stream, mean of 20, max over ranks (nccl backend only)"}
 
+    exit_code = 0
     if rank == 0:
         dt = float(np.median(block_s))
         value = n_total * args.steps / dt
@@ -890,7 +1061,9 @@ def run_rank(args) -> int:
                        "candidates_per_gpu": per_rank, "total_candidates": n_total,
                        "sharding": f"contiguous blocks over {world} GPU(s), one all-gather of 32-B records ({args.backend})",
                        "pipeline": f"{n_pipe} scorer context(s)/HIP stream(s) per GPU; batch k runs whole on context k mod {n_pipe}"},
-            "timing": {"repeats": len(block_s), "block_ms_per_step": [b / args.steps * 1e3 for b in block_s],
+            "timing": {"repeats": len(block_s), "timed_seconds_total": float(sum(block_s)),
+                       "block_ms_per_step": [round(b / args.steps * 1e3, 5) for b in block_s],
+                       "block_ms_per_step_p10_p90": [float(np.percentile(block_s, 10) / args.steps * 1e3), float(np.percentile(block_s, 90) / args.steps * 1e3)],
                        "median_ms_per_step": dt / args.steps * 1e3, "min_ms_per_step": min(block_s) / args.steps * 1e3,
                        "value_from": "median block", "kernel_events_in_block": len(block_s) - 1, "value_at_min": n_total * args.steps / min(block_s)},
             "roofline": roofline,
@@ -905,16 +1078,25 @@ def run_rank(args) -> int:
                              "order_is_a_permutation": ranked["order_is_a_permutation"], "costs_ascending": ranked["costs_ascending"],
                              "note": "score (+ all-gather) + fs_rank_candidates_dev over the full list on the same stream, path columns resident; "
                                      "one block of K steps; never `value`"} if ranked else None),
-            "multi_gpu": multi, "rehearse_multi": bool(args.rehearse_multi) or None,
+            "multi_gpu": multi, "strong_scaling": strong, "rehearse_multi": bool(args.rehearse_multi) or None,
             "other_operating_points": extra or None,
         }
         print(json.dumps(line), flush=True)
+        # a value next to a red gate must not look like success to whoever runs this: the line is printed (the figures are
+        # evidence either way), the exit code says the gate failed
+        red = red_gates(line)
+        if red:
+            print(f"[bench] PARITY GATE RED: {', '.join(red)} — exit code 5", file=sys.stderr, flush=True)
+            exit_code = 5
     if multi_path:
+        code = torch.tensor([exit_code], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(code, op=dist.ReduceOp.MAX)                 # every rank leaves with rank 0's verdict
+        exit_code = int(code[0])
         dist.barrier()
         dist.destroy_process_group()
     for c in scs:
         c.close()
-    return 0
+    return exit_code
 
 
 def main(argv=None) -> int:

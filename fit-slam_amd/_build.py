@@ -67,27 +67,73 @@ def hipcc() -> str:
 
 
 STAMP = LIB + ".stamp"
+OBJ_STAMPS = os.path.join(CSRC, f"objects{SUFFIX}.stamp.json")
 
 
-def source_digest() -> str:
-    """What the library was built from: SHA-256 over the sources, the headers and the compiler flags."""
+def _sha256_file(path: str) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def _inputs_digest(names) -> str:
     import hashlib
     h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
-    for name in SOURCES + HEADERS:
+    for name in names:
         h.update(name.encode())
         h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()
 
 
+def source_digest() -> str:
+    """What the library was built from: SHA-256 over the sources, the headers and the compiler flags."""
+    return _inputs_digest(SOURCES + HEADERS)
+
+
+def object_digest(src: str) -> str:
+    """What ONE object was compiled from: its source, every header and the flags."""
+    return _inputs_digest([src] + HEADERS)
+
+
+def _read_stamp():
+    """(source digest, library SHA-256 or None) as the last successful link wrote them."""
+    lines = open(STAMP).read().split()
+    return (lines[0] if lines else ""), (lines[1] if len(lines) > 1 else None)
+
+
 def needs_build() -> bool:
     """By CONTENT, not by modification time: a copy of the tree (the GPU box's snapshot, a fresh checkout next to a built
-    library) may order the timestamps any way it likes — N ranks starting there must not all decide to rebuild."""
+    library) may order the timestamps any way it likes — N ranks starting there must not all decide to rebuild.  The stamp
+    names the sources AND the library file it was written for: a library that is not the one the stamp describes (a stale
+    file copied over a fresh stamp, a truncated copy) is out of date too."""
     if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
     try:
-        return open(STAMP).read().strip() != source_digest()
+        src, lib = _read_stamp()
+        return src != source_digest() or lib != _sha256_file(LIB)
     except OSError:
         return True
+
+
+def _load_obj_stamps() -> dict:
+    import json
+    try:
+        d = json.load(open(OBJ_STAMPS))
+        return d if isinstance(d, dict) else {}
+    except Exception:
+        return {}
+
+
+def _object_current(src: str, obj: str, stamps: dict) -> bool:
+    """An object is reused only when the stamp says it was compiled from exactly these inputs AND the file on disk is the
+    one that compile produced.  Modification times decide nothing."""
+    rec = stamps.get(os.path.basename(obj))
+    if not rec or not os.path.exists(obj):
+        return False
+    return rec.get("inputs") == object_digest(src) and rec.get("object") == _sha256_file(obj)
 
 
 def _parse_resource_remarks(text: str) -> dict:
@@ -144,13 +190,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 def _build_locked(force: bool, verbose: bool) -> str:
+    import json
     cc = hipcc()
     objs = []
+    stamps = _load_obj_stamps()
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", SUFFIX + ".o"))
         src_path = os.path.join(CSRC, src)
-        hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS + [os.path.abspath(__file__)])
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src_path), hdr_t):
+        if force or not _object_current(src, obj, stamps):
             cmd = [cc, *HIPCC_FLAGS, "-c", src_path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr, flush=True)
@@ -165,6 +212,11 @@ def _build_locked(force: bool, verbose: bool) -> str:
             if res.returncode != 0:
                 raise subprocess.CalledProcessError(res.returncode, cmd)
             _record_resources(src, usage)
+            # (written object by object: an interrupted build keeps what it finished)
+            stamps[os.path.basename(obj)] = {"inputs": object_digest(src), "object": _sha256_file(obj)}
+            tmp_s = OBJ_STAMPS + f".tmp{os.getpid()}"
+            json.dump(stamps, open(tmp_s, "w"), indent=1, sort_keys=True)
+            os.replace(tmp_s, OBJ_STAMPS)
         objs.append(obj)
     # linked under a temporary name and renamed into place: a process that loads the library while another one links never
     # sees a half-written file
@@ -175,7 +227,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
     subprocess.check_call(cmd, stdout=sys.stderr)
     os.replace(tmp, LIB)
     with open(STAMP + f".tmp{os.getpid()}", "w") as f:
-        f.write(source_digest() + "\n")
+        f.write(source_digest() + "\n" + _sha256_file(LIB) + "\n")
     os.replace(STAMP + f".tmp{os.getpid()}", STAMP)
     return LIB
 

@@ -214,6 +214,20 @@ def make_workload(name: str, *, n_cand: int | None = None, n_landmarks: int | No
                     polygon=(origin[0], origin[1], origin[0] + n * res, origin[1] + n * res))
 
 
+def poses_from_yaw(goal_xyz, yaw) -> np.ndarray:
+    """pose7 rows (x, y, z, qx, qy, qz, qw) of fs_score_fim for goal points and yaw angles: the quaternion
+    nav2_util::geometry_utils::orientationAroundZAxis builds (tf2 setRPY(0, 0, yaw): (0, 0, sin(yaw / 2), cos(yaw / 2)); call
+    sites DEP/include/.../util/GeometryUtils.hpp:112-124, DEP/src/Frontier.cpp:54) — libm's sin / cos in double, one by one."""
+    import math
+    goal = np.asarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((goal.shape[0], 7), dtype=np.float64)
+    out[:, :3] = goal
+    for i, y in enumerate(np.asarray(yaw, dtype=np.float64).reshape(-1)):
+        h = float(y) * 0.5
+        out[i, 5], out[i, 6] = math.sin(h), math.cos(h)
+    return out
+
+
 def candidate_block(w: Workload, name: str, block: int, n_cand: int | None = None):
     """Block `block` of a longer candidate list over the SAME map and cloud (weak scaling: rank r scores block r, and needs
     nothing of the other ranks' blocks).  Block 0 is the workload's own list; the others are drawn from the same frontier cells

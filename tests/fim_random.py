@@ -16,6 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 fs = importlib.import_module("fit-slam_amd")
+parity = importlib.import_module("fit-slam_amd.parity")
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle  # noqa: E402  (the checker; this tool is test infrastructure)
 
@@ -75,14 +76,13 @@ def main():
         tr = np.maximum(np.abs(want["trace"]), 1e-6)
         assert np.max(np.abs(got["trace"] - want["trace"]) / tr) <= REL, tag
         worst = max(worst, float(err.max()))
-        # D-optimality: plain 1e-4 of max(1, |log det|) plus the input-rounding floor cond(F) * 2^-24 (tests/test_gpu_parity.py)
+        # D-optimality: the one rule of fit-slam_amd/parity.py (plain 1e-4 of max(1, |log det|) plus kappa(F) * 2^-24)
+        gate = parity.logdet_gate(got["logdet"], want["logdet"], want["fim"])
         both = np.isfinite(want["logdet"]) & np.isfinite(got["logdet"])
+        e_ld = np.abs(got["logdet"][both] - want["logdet"][both])
+        assert gate["logdet_share_within_rule"] == 1.0, (tag, gate)
         if both.any():
-            lam = np.linalg.eigvalsh(want["fim"][both])
-            cond = lam[:, -1] / np.maximum(lam[:, 0], 1e-300)
-            tol = REL * np.maximum(1.0, np.abs(want["logdet"][both])) + 2.0 ** -24 * cond
-            e_ld = np.abs(got["logdet"][both] - want["logdet"][both])
-            assert np.all(e_ld <= tol), (tag, float((e_ld / tol).max()))
+            cond = parity.fim_condition(want["fim"][both])
             worst_ld = max(worst_ld, float((e_ld / np.maximum(1.0, np.abs(want["logdet"][both])))[cond < 1e3].max(initial=0.0)))
         # the same poses asked for info_ref alone: the INFO_ONLY worker (exact table-box cull in a general camera frame) where the
         # table is finite and the cone common, the general one otherwise — n_voxels exactly, the information to the same tolerance
