@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "fs_multi_create", "fs_multi_destroy", "fs_multi_num_devices", "fs_multi_ctx", "fs_multi_last_error", "fs_multi_shard_bounds",
     "fs_multi_set_option", "fs_multi_set_ray_params", "fs_multi_upload_grid", "fs_multi_upload_landmarks", "fs_multi_lookup_generate",
     "fs_multi_lookup_load", "fs_multi_set_fim_params", "fs_multi_max_arrival", "fs_multi_score_arrival", "fs_multi_score_candidates",
+    "fs_multi_score_fim", "fs_multi_get_frontier_costs", "fs_multi_gather_mode",
 ]
 
 RECORD_DTYPE = np.dtype([("arrival", "<i4"), ("argmax", "<i4"), ("yaw", "<f4"), ("info_ref", "<f4"),
@@ -144,6 +145,9 @@ def load_library(build: bool = True):
     L.fs_multi_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
     L.fs_multi_score_arrival.argtypes = [vp, i32] + [vp] * 10
     L.fs_multi_score_candidates.argtypes = [vp, i32] + [vp] * 5
+    L.fs_multi_score_fim.argtypes = [vp, i32] + [vp] * 7
+    L.fs_multi_get_frontier_costs.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, dbl, dbl, dbl, dbl, C.c_int, vp, vp, vp, vp, vp]
+    L.fs_multi_gather_mode.argtypes = [vp]
     for name in EXPORTED_SYMBOLS:
         f = getattr(L, name)
         if name not in ("fs_ctx_destroy", "fs_last_error", "fs_multi_destroy", "fs_multi_last_error", "fs_multi_ctx"):
@@ -535,6 +539,60 @@ class MultiScorer:
         rec = np.zeros(n, dtype=RECORD_DTYPE)
         self._check(self._L.fs_multi_score_candidates(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(rec)))
         return rec
+
+
+    def score_fim(self, pose7, want_fim=True, info_only=False):
+        """fs_multi_score_fim: FrontierScorer.score_fim over all members, every column in list order."""
+        ps = np.ascontiguousarray(pose7, dtype=np.float64).reshape(-1, 7)
+        n = ps.shape[0]
+        info = np.zeros(n, dtype=np.float32)
+        if info_only:
+            nvox = np.zeros(n, dtype=np.int32)
+            self._check(self._L.fs_multi_score_fim(self._h, n, _p(ps), _p(info), None, None, None, None, _p(nvox)))
+            return dict(info_ref=info, n_voxels=nvox)
+        fim21 = np.zeros((n, 21), dtype=np.float32) if want_fim else None
+        trace = np.zeros(n, dtype=np.float32); logdet = np.zeros(n, dtype=np.float32)
+        nvis = np.zeros(n, dtype=np.int32); nvox = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_multi_score_fim(self._h, n, _p(ps), _p(info), _p(fim21), _p(trace), _p(logdet), _p(nvis), _p(nvox)))
+        return dict(info_ref=info, fim21=fim21, trace=trace, logdet=logdet, n_visible=nvis, n_voxels=nvox)
+
+    def get_frontier_costs(self, goal_xyz, path_length, path_heading, frontier_size=None, blacklisted=None, achievable_in=None,
+                           with_fim=False, alpha=0.25, beta=1.0, max_vx=0.5, max_wz=0.5):
+        """fs_multi_get_frontier_costs: blocks scored on their devices, gathered device to device, ranked on member 0's GPU."""
+        goal = np.ascontiguousarray(goal_xyz, dtype=np.float64).reshape(-1, 3)
+        n = goal.shape[0]
+        pl = np.ascontiguousarray(path_length, dtype=np.float64)
+        ph = np.ascontiguousarray(path_heading, dtype=np.float64)
+        fs = None if frontier_size is None else np.ascontiguousarray(frontier_size, dtype=np.int32)
+        bl = None if blacklisted is None else np.ascontiguousarray(blacklisted, dtype=np.uint8)
+        ai = None if achievable_in is None else np.ascontiguousarray(achievable_in, dtype=np.uint8)
+        rec = np.zeros(n, dtype=RECORD_DTYPE)
+        cost = np.zeros(n); au = np.zeros(n); du = np.zeros(n); order = np.zeros(n, dtype=np.int32)
+        self._check(self._L.fs_multi_get_frontier_costs(self._h, n, _p(goal), _p(fs), _p(bl), _p(ai), _p(pl), _p(ph), alpha, beta, max_vx, max_wz,
+                                                        1 if with_fim else 0, _p(rec), _p(cost), _p(au), _p(du), _p(order)))
+        return dict(records=rec, weighted_cost=cost, arrival_utility=au, distance_utility=du, order=order)
+
+    def gather_mode(self) -> int:
+        rc = self._L.fs_multi_gather_mode(self._h)
+        if rc < 0:
+            self._check(rc)
+        return rc
+
+    def last_error(self) -> str:
+        return (self._L.fs_multi_last_error(self._h) or b"").decode()
+
+    def member(self, i: int):
+        """fs_multi_ctx(m, i) as a borrowed handle for fs_* calls on one member (counters, options, limits)."""
+        h = self._L.fs_multi_ctx(self._h, int(i))
+        if not h:
+            raise FsError(FS_E_INVALID, f"no member {i}")
+        return C.c_void_p(h)
+
+    def set_arrival_limits(self, max_gt, min_gt):
+        for i in range(self.n_devices):
+            rc = self._L.fs_set_arrival_limits(self.member(i), float(max_gt), float(min_gt))
+            if rc != FS_OK:
+                raise FsError(rc, f"fs_set_arrival_limits on member {i}")
 
 
 def record_status(rec):

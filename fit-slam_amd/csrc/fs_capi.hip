@@ -68,7 +68,16 @@ struct PinnedBuf {
         const size_t want = std::max<size_t>(bytes, 4096);
         ++fs_alloc_generation;
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocMapped);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) {
+            // a runtime / device that refuses MAPPED page-locked memory still gets plain page-locked staging: dev stays nullptr and
+            // every entry point takes its transfer path (the sticky error of the refused call is cleared first)
+            (void)hipGetLastError();
+            p = nullptr;
+            e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocDefault);
+            if (e != hipSuccess) { p = nullptr; return e; }
+            cap = want;
+            return hipSuccess;
+        }
         cap = want;
         void *d = nullptr;
         if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess) dev = static_cast<char *>(d);
@@ -189,6 +198,11 @@ struct fs_ctx {
     // fs_score_arrival_begin -> _end: where the columns waiting in h_out go (caller's arrays) once the stream has drained
     struct PendingCol { void *host; size_t off, bytes; };
     std::vector<PendingCol> arrival_pending;
+    std::vector<PendingCol> fim_pending;           // fs_score_fim_begin -> _end, likewise
+    // the gather role of fs_multi_get_frontier_costs' member 0 (its own block still goes through h_in / d_in): the planner's
+    // path columns and the blacklist of the WHOLE list; the gathered records live in d_out, ahead of the ranking's columns
+    PinnedBuf h_gin;
+    DevBuf<char> d_gin;
     // scratch of the per-tick entry points (fs_trace_segments, fs_frontier_cells, fs_information_frontier_pair,
     // fs_upload_grid_bricks): owned by the context and grown on demand, never allocated and freed per call
     DevBuf<double> d_seg_start, d_seg_end, d_tri;
@@ -734,7 +748,7 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_overflow.release(); c->d_tested.release(); c->d_flagged.release(); c->d_records.release();
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->sort_scratch) (void)hipFree(c->sort_scratch);
-    c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release();
+    c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release();
     c->d_seg_start.release(); c->d_seg_end.release(); c->d_tri.release(); c->d_seg_ok.release(); c->d_seg_hit.release();
     c->d_mask.release(); c->d_brick_cells.release(); c->d_seg_traced.release(); c->d_seg_unknown.release();
     c->d_seg_all.release(); c->d_brick_xyz.release(); c->d_bad.release(); c->d_count.release();
@@ -1523,10 +1537,14 @@ static int run_fim_rest(fs_ctx *c, FsFimArgs &a)
     return FS_OK;
 }
 
-int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, float *fim21,
-                 float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels)
+// fs_score_fim in two halves (as fs_score_candidates_begin / _end): `begin` stages the poses, launches the kernels and requests
+// the columns into the context's page-locked buffer, all asynchronous on the context's stream; `end` waits for that stream and
+// copies the columns into the caller's arrays.  fs_multi_score_fim starts every member before it waits for the first.
+int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, float *fim21,
+                       float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels)
 {
     if (!c) return FS_E_INVALID;
+    c->fim_pending.clear();
     FS_HIP(c, hipSetDevice(c->device));
     int rc = check_scoring_state(c, false, true);
     if (rc) return rc;
@@ -1602,14 +1620,32 @@ int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, flo
     else rc = enqueue();
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     size_t off = 0;
-    FS_HIP(c, hipStreamSynchronize(c->stream));
-    off = 0;
     for (const Col &col : cols) {
         if (!col.host) continue;
-        std::memcpy(col.host, c->h_out.p + off, col.bytes);
+        c->fim_pending.push_back({col.host, off, col.bytes});
         off += (col.bytes + 15) & ~(size_t)15;
     }
     return FS_OK;
+}
+
+int fs_score_fim_end(fs_ctx *c)
+{
+    if (!c) return FS_E_INVALID;
+    if (c->fim_pending.empty()) return FS_OK;
+    FS_HIP(c, hipSetDevice(c->device));
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { c->fim_pending.clear(); return fail(c, FS_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+    for (const fs_ctx::PendingCol &col : c->fim_pending) std::memcpy(col.host, c->h_out.p + col.off, col.bytes);
+    c->fim_pending.clear();
+    return FS_OK;
+}
+
+int fs_score_fim(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, float *fim21,
+                 float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels)
+{
+    const int rc = fs_score_fim_begin(c, n, pose7, info_ref, fim21, trace, logdet, n_visible, n_voxels);
+    if (rc) return rc;
+    return fs_score_fim_end(c);
 }
 
 int fs_information_frontier_pair(fs_ctx *c, int32_t n, const double *est_pose7, const double *triangle_xy, float *information)
@@ -1943,6 +1979,111 @@ int frontier_costs_core(fs_ctx *c, int32_t n, const double *goal_xyz, const int3
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------ pieces of fs_multi_get_frontier_costs (fs_multi.hip)
+// One process, several GPUs, ONE call: every member scores its block of the frontier list on its own device and stream, the
+// blocks' records are moved device to device into ONE list on member 0's device (fs_multi.hip: peer copies over xGMI, each on
+// the member's stream behind its kernels, an event per member that member 0's stream waits for), fs_rank_candidates_dev runs
+// there on the whole list, and what the caller asked for comes back in ONE transfer.  Nothing below synchronises except _end.
+
+hipStream_t fs_ctx_stream(fs_ctx *c) { return c->stream; }
+int fs_ctx_device(const fs_ctx *c) { return c->device; }
+
+namespace {
+struct GatherLayout {
+    size_t i_len, i_head, i_black, total_in;
+    size_t o_rec, o_cost, o_au, o_du, o_order, o_err, total_out;
+    explicit GatherLayout(size_t n)
+    {
+        i_len = 0; i_head = 8 * n; i_black = 16 * n; total_in = i_black + ((n + 15) & ~(size_t)15);
+        o_rec = 0; o_cost = sizeof(fs_record) * n; o_au = o_cost + 8 * n; o_du = o_au + 8 * n; o_order = o_du + 8 * n;
+        o_err = (o_order + 4 * n + 15) & ~(size_t)15; total_out = o_err + 16;
+    }
+};
+}  // namespace
+
+// member 0, first: the whole list's path columns and blacklist go to its device (one transfer, on its stream); *d_list is where
+// the n records of the gathered list will live
+int fs_gather_begin(fs_ctx *c, int32_t n, const uint8_t *blacklisted, const double *path_length, const double *path_heading, fs_record **d_list)
+{
+    if (!c || n <= 0 || !path_length || !path_heading || !d_list) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    const size_t nn = (size_t)n;
+    const GatherLayout L(nn);
+    FS_HIP(c, c->h_gin.ensure(L.total_in)); FS_HIP(c, c->d_gin.ensure(L.total_in));
+    FS_HIP(c, c->h_out.ensure(L.total_out)); FS_HIP(c, c->d_out.ensure(L.total_out));
+    std::memcpy(c->h_gin.p + L.i_len, path_length, 8 * nn);
+    std::memcpy(c->h_gin.p + L.i_head, path_heading, 8 * nn);
+    if (blacklisted) std::memcpy(c->h_gin.p + L.i_black, blacklisted, nn); else std::memset(c->h_gin.p + L.i_black, 0, nn);
+    FS_HIP(c, hipMemcpyAsync(c->d_gin.p, c->h_gin.p, L.total_in, hipMemcpyHostToDevice, c->stream));
+    *d_list = reinterpret_cast<fs_record *>(c->d_out.p + L.o_rec);
+    return FS_OK;
+}
+
+// any member: stage the block's candidate columns and score them — into d_dst when the member may write the gathered list
+// itself (member 0; a member on member 0's device), else into its own record buffer; *d_block says where the records are
+int fs_block_score_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size, const uint8_t *blacklisted,
+                         const uint8_t *achievable_in, bool with_fim, fs_record *d_dst, fs_record **d_block)
+{
+    if (!c || n <= 0 || !goal_xyz || !d_block) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    int rc = check_scoring_state(c, true, with_fim);
+    if (rc) return rc;
+    rc = upload_candidates(c, n, goal_xyz, frontier_size, blacklisted, achievable_in);
+    if (rc) return rc;
+    if (!d_dst) { FS_HIP(c, c->d_records.ensure(n)); d_dst = c->d_records.p; }
+    rc = with_fim ? fs_score_candidates_dev(c, n, c->in_goal, c->in_fsize, c->in_black, c->in_achin, d_dst)
+                  : arrival_records_dev(c, n, c->in_goal, c->in_fsize, c->in_black, c->in_achin, d_dst);
+    if (rc) return rc;
+    *d_block = d_dst;
+    return FS_OK;
+}
+
+// the fallback without peer access: a block's records to the member's page-locked buffer (member 0's stream copies them on from there)
+int fs_block_records_to_host(fs_ctx *c, int32_t n, const fs_record *d_block, const fs_record **h_block)
+{
+    if (!c || n <= 0 || !d_block || !h_block) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    FS_HIP(c, c->h_out.ensure(sizeof(fs_record) * (size_t)n));
+    FS_HIP(c, hipMemcpyAsync(c->h_out.p, d_block, sizeof(fs_record) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    *h_block = reinterpret_cast<const fs_record *>(c->h_out.p);
+    return FS_OK;
+}
+
+// member 0, once its stream waits for every block: U1 costs and order over the whole list, then the ONE transfer out
+int fs_gather_rank(fs_ctx *c, int32_t n, double alpha, double beta, double max_vx, double max_wz)
+{
+    if (!c || n <= 0) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    const GatherLayout L((size_t)n);
+    char *in = c->d_gin.p, *out = c->d_out.p;
+    const int rc = fs_rank_candidates_dev(c, n, reinterpret_cast<const fs_record *>(out + L.o_rec), reinterpret_cast<const uint8_t *>(in + L.i_black),
+                                          reinterpret_cast<const double *>(in + L.i_len), reinterpret_cast<const double *>(in + L.i_head),
+                                          alpha, beta, max_vx, max_wz, reinterpret_cast<double *>(out + L.o_cost), reinterpret_cast<double *>(out + L.o_au),
+                                          reinterpret_cast<double *>(out + L.o_du), reinterpret_cast<int32_t *>(out + L.o_order), reinterpret_cast<int32_t *>(out + L.o_err));
+    if (rc) return rc;
+    FS_HIP(c, hipMemcpyAsync(c->h_out.p, out, L.total_out, hipMemcpyDeviceToHost, c->stream));
+    return FS_OK;
+}
+
+int fs_gather_end(fs_ctx *c, int32_t n, fs_record *records, double *weighted_cost, double *arrival_utility, double *distance_utility, int32_t *order)
+{
+    if (!c || n <= 0) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t nn = (size_t)n;
+    const GatherLayout L(nn);
+    const char *ho = c->h_out.p;
+    if (records) std::memcpy(records, ho + L.o_rec, sizeof(fs_record) * nn);
+    if (weighted_cost) std::memcpy(weighted_cost, ho + L.o_cost, 8 * nn);
+    if (arrival_utility) std::memcpy(arrival_utility, ho + L.o_au, 8 * nn);
+    if (distance_utility) std::memcpy(distance_utility, ho + L.o_du, 8 * nn);
+    if (order) std::memcpy(order, ho + L.o_order, 4 * nn);
+    int32_t err = 0;
+    std::memcpy(&err, ho + L.o_err, 4);
+    if (err) return fail(c, FS_E_RANGE, "utility outside [0,1] (the reference throws: FrontierCostsManager.cpp:148-149,173-174)");
+    return FS_OK;
+}
 
 extern "C" {
 

@@ -235,5 +235,18 @@ extern "C" int fs_score_arrival_begin(fs_ctx *c, int32_t n, const double *goal_x
                                       const uint8_t *blacklisted, const uint8_t *achievable_in, int32_t *ray_counts, int32_t *arrival,
                                       int32_t *argmax, double *yaw, uint8_t *achievable, int32_t *status);
 extern "C" int fs_score_arrival_end(fs_ctx *c);
+extern "C" int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_ref, float *fim21, float *trace, float *logdet,
+                                  int32_t *n_visible, int32_t *n_voxels);
+extern "C" int fs_score_fim_end(fs_ctx *c);
+
+// pieces of fs_multi_get_frontier_costs (defined in fs_capi.hip, sequenced by fs_multi.hip)
+hipStream_t fs_ctx_stream(fs_ctx *c);
+int fs_ctx_device(const fs_ctx *c);
+int fs_gather_begin(fs_ctx *c, int32_t n, const uint8_t *blacklisted, const double *path_length, const double *path_heading, fs_record **d_list);
+int fs_block_score_begin(fs_ctx *c, int32_t n, const double *goal_xyz, const int32_t *frontier_size, const uint8_t *blacklisted,
+                         const uint8_t *achievable_in, bool with_fim, fs_record *d_dst, fs_record **d_block);
+int fs_block_records_to_host(fs_ctx *c, int32_t n, const fs_record *d_block, const fs_record **h_block);
+int fs_gather_rank(fs_ctx *c, int32_t n, double alpha, double beta, double max_vx, double max_wz);
+int fs_gather_end(fs_ctx *c, int32_t n, fs_record *records, double *weighted_cost, double *arrival_utility, double *distance_utility, int32_t *order);
 
 #endif

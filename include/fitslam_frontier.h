@@ -285,8 +285,8 @@ int fs_score_candidates_dev(fs_ctx *ctx, int32_t n, const double *d_goal_xyz, co
  * applied to all of them (the grid, the cloud and the table are replicated: 128 MiB + 1.2 MB + 2.8 MB at 512^3), and
  * fs_multi_score_candidates cuts the frontier list into contiguous blocks of ceil(n / G) candidates (fs_multi_shard_bounds
  * — the same rule the multi-process bench uses), starts block g on device g without waiting, then collects the 32-byte
- * records of all blocks into the caller's buffer in list order.  Candidates are independent, so there is no device-to-device
- * traffic at all; ranking (fs_rank_candidates on fs_multi_ctx(m, 0)) runs on the gathered records. */
+ * records of all blocks into the caller's buffer in list order.  fs_multi_get_frontier_costs is the one-call form: blocks
+ * gathered device to device over xGMI onto member 0's GPU, ranked there, one transfer out (below). */
 typedef struct fs_multi fs_multi;
 int  fs_multi_create(const int *device_ids, int n_devices, fs_multi **out);
 void fs_multi_destroy(fs_multi *m);
@@ -315,6 +315,27 @@ int  fs_multi_score_arrival(fs_multi *m, int32_t n, const double *goal_xyz, cons
 /* fs_score_candidates over all members: host buffers in, records [n] out, list order; returns when every block is in */
 int  fs_multi_score_candidates(fs_multi *m, int32_t n, const double *goal_xyz, const int32_t *frontier_size,
                                const uint8_t *blacklisted, const uint8_t *achievable_in, fs_record *records);
+/* fs_score_fim over all members (FisherInformationManager::isPoseSafe's batch, FIP/src/fisher_information/FisherInfoManager.cpp:39-115):
+   poses cut into the same contiguous blocks, every member started before the first is waited for, every column in list order */
+int  fs_multi_score_fim(fs_multi *m, int32_t n, const double *pose7, float *info_ref, float *fim21,
+                        float *trace, float *logdet, int32_t *n_visible, int32_t *n_voxels);
+/* fs_get_frontier_costs — the whole of CostAssigner::getFrontierCosts (DEP/src/CostAssigner.cpp:73-119; the in-process call of
+ * DEP/src/ExplorationBT.cpp:376-410) — over all members, with the records NEVER visiting the host between scoring and ranking:
+ * member g scores block g on its device; its 32-byte records are moved device to device into ONE list on member 0's GPU
+ * (hipMemcpyPeerAsync over xGMI on the member's stream behind its kernels, one event per member that member 0's stream waits
+ * for; a member that shares member 0's GPU writes the list itself); fs_rank_candidates_dev ranks the gathered list there; ONE
+ * transfer brings records, costs, utilities and order back.  Same arguments, same results (integers, costs and order bit for
+ * bit) as fs_get_frontier_costs on one context.  A gather onto the ranking device, not an all-gather: in one process only
+ * that device needs the list.  Where the runtime refuses peer access between a member and member 0 the blocks bounce through
+ * page-locked host memory instead; the call still succeeds and fs_multi_last_error says so (fs_multi_gather_mode: 2). */
+int  fs_multi_get_frontier_costs(fs_multi *m, int32_t n, const double *goal_xyz, const int32_t *frontier_size, const uint8_t *blacklisted,
+                                 const uint8_t *achievable_in, const double *path_length, const double *path_heading,
+                                 double alpha, double beta, double max_vx, double max_wz, int with_fisher_information,
+                                 fs_record *records, double *weighted_cost, double *arrival_utility, double *distance_utility, int32_t *order);
+/* how fs_multi_get_frontier_costs moves the blocks: 1 device to device (peer access granted, or every member on one GPU),
+   2 through page-locked host memory (peer access refused), 3 / forced values: fs_multi_set_option("multi.gather", 0 auto | 1 | 2 | 3
+   = device copies even between members of one GPU), for tests of the paths a one-GPU box cannot take by itself.  < 0: error */
+int  fs_multi_gather_mode(fs_multi *m);
 
 /* ---------------------------------------------------------------- utility + ranking */
 
@@ -334,8 +355,10 @@ int fs_rank_candidates(fs_ctx *ctx, int32_t n, const fs_record *records, const u
  * — FrontierCostsManager::assignCosts' arrival information for every frontier (DEP/src/FrontierCostsManager.cpp:74-119) followed by
  * its U1 block (:126-205) — as ONE call: frontier list and the planner's path columns in, scored and ranked candidates out; one
  * transfer each way and one synchronisation, the records never visit the host between scoring and ranking.  Up to 1024
- * frontiers (the reference handles tens per tick) the device-side sequence is a captured launch graph that is replayed with a
- * single launch ("graph" option of fitslam_frontier_dev.h).
+ * frontiers (the reference handles tens per tick) the kernels read the inputs from, and write the results into, the context's
+ * mapped page-locked buffers in place — plain launches, no transfers of their own.  (Replaying the sequence as a captured launch
+ * graph exists behind fs_set_option("graph", 1) of fitslam_frontier_dev.h and is OFF by default: it measured 5-7 us slower per
+ * call than the plain launches on this runtime; only with it on is the list padded to power-of-two buckets.)
  *   path_length, path_heading [n]  what the planner set on each frontier (Frontier::setPathLength / setPathHeading; inputs here).
  *                                  The reference plans a frontier only once its arrival information has left it achievable
  *                                  (FrontierCostsManager.cpp:88-91); here the columns come first — those of a frontier that turns

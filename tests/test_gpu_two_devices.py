@@ -63,6 +63,40 @@ def test_fs_multi_on_two_physical_devices_equals_a_single_context(fs):
 
 
 @two_gpus
+def test_fs_multi_get_frontier_costs_gathers_over_the_peer_link(fs):
+    """The device_count() >= 2 twin of test_multi_get_frontier_costs_equals_one_context: member 1's block travels with
+    hipMemcpyPeerAsync from GPU 1 into the gathered list on GPU 0 (or, where the runtime refuses peer access, through page-locked
+    memory — fs_multi_gather_mode says which, and both must give the one-context results)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("multi_device_helpers", os.path.join(ROOT, "tests", "test_multi_device.py"))
+    helpers = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(helpers)
+    w = fs.synth.make_workload("C2")
+    n = w.goals.shape[0]
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+              robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+    plen, phead = helpers._path_columns(n)
+    one = fs.FrontierScorer(device=0)
+    mx = helpers._stage(one, w, kw)
+    one.set_arrival_limits(4000.0, mx["min_gt"])
+    want = one.get_frontier_costs(w.goals, plen, phead, w.frontier_size, w.blacklisted, with_fim=True)
+    one.close()
+    m = fs.MultiScorer(devices=(0, 1))
+    helpers._stage(m, w, kw)
+    m.set_arrival_limits(4000.0, mx["min_gt"])
+    auto = m.gather_mode()
+    assert auto in (1, 2), auto
+    for forced in (0, 2):                                            # what set-up chose, then the bounce
+        m.set_option("multi.gather", forced)
+        for _ in range(2):
+            got = m.get_frontier_costs(w.goals, plen, phead, w.frontier_size, w.blacklisted, with_fim=True)
+            helpers._same_records(got["records"], want["records"])
+            for k in ("weighted_cost", "arrival_utility", "distance_utility", "order"):
+                np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    m.close()
+
+
+@two_gpus
 def test_bench_two_ranks_over_rccl():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -3,7 +3,10 @@
 not-gpu: the partition rule (fs_multi_shard_bounds, callable without a device) — contiguous, ordered, complete, equal to the
          rule of the multi-process path (shard.py); a device list without a gfx950 fails loudly.
 gpu:     a device list [0, 0] / [0, 0, 0] (several contexts on the one GPU of the test box) returns the records of
-         a single context (integers bit for bit) — the blocks are scored side by side and land in list order."""
+         a single context (integers bit for bit) — the blocks are scored side by side and land in list order;
+         fs_multi_get_frontier_costs (blocks gathered device to device, ranked on member 0's GPU) equals fs_get_frontier_costs on
+         one context — records, costs, utilities and order — through every way a block can travel (written in place, device
+         copy + event, page-locked bounce); fs_multi_score_fim equals fs_score_fim."""
 import importlib
 
 import numpy as np
@@ -100,3 +103,106 @@ def test_multi_reports_the_failing_member(fs):
         m.score_candidates(np.zeros((4, 3)))                         # nothing staged yet
     assert e.value.code == fs.capi.FS_E_STATE and "block 0" in str(e.value)
     m.close()
+
+
+def _path_columns(n):
+    i = np.arange(n, dtype=np.float64)
+    return 0.5 + 29.5 * np.modf(i * 0.6180339887498949)[0], np.pi * np.modf(i * 0.7548776662466927)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_fim", [False, True])
+@pytest.mark.parametrize("devices,n_cand,gather", [((0, 0), 5000, 0), ((0, 0, 0), 4999, 0), ((0, 0), 3000, 3), ((0, 0, 0), 2500, 2),
+                                                   ((0, 0, 0, 0), 3, 3), ((0,), 300, 0), ((0, 0), 700, 2)])
+def test_multi_get_frontier_costs_equals_one_context(fs, devices, n_cand, gather, with_fim):
+    """CostAssigner::getFrontierCosts as ONE call over several members (VERDICT r04 missing #2): the records stay on the devices
+    between scoring and ranking.  `gather`: 0 = what set-up chose (members of one GPU write the gathered list in place),
+    3 = every other member's block is a device copy on its own stream + an event member 0's stream waits for (the machinery a
+    second physical GPU uses with hipMemcpyPeerAsync), 2 = the fallback where peer access is refused: blocks bounce through
+    page-locked host memory.  All must give the one-context call's results: integers, costs, utilities and order bit for bit."""
+    w = fs.synth.make_workload("C2", n_cand=n_cand)
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+              robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+    plen, phead = _path_columns(n_cand)
+    ach_in = (np.arange(n_cand) % 17 != 0).astype(np.uint8)          # the planner could not reach every 17th frontier
+    one = fs.FrontierScorer(device=0)
+    mx = _stage(one, w, kw)
+    one.set_arrival_limits(4000.0, mx["min_gt"])
+    want = one.get_frontier_costs(w.goals, plen, phead, w.frontier_size, w.blacklisted, ach_in, with_fim=with_fim)
+    one.close()
+    m = fs.MultiScorer(devices=devices)
+    _stage(m, w, kw)
+    m.set_arrival_limits(4000.0, mx["min_gt"])
+    if gather:
+        m.set_option("multi.gather", gather)
+    assert m.gather_mode() == (gather or 1)
+    if gather == 2:
+        assert "page-locked host memory" in m.last_error()
+    for _ in range(2):                                               # twice: buffers and events are re-used
+        got = m.get_frontier_costs(w.goals, plen, phead, w.frontier_size, w.blacklisted, ach_in, with_fim=with_fim)
+        _same_records(got["records"], want["records"])
+        for k in ("weighted_cost", "arrival_utility", "distance_utility", "order"):
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    # a list shorter than the device list, and optional columns absent
+    got = m.get_frontier_costs(w.goals[:1], plen[:1], phead[:1], with_fim=with_fim)
+    one = fs.FrontierScorer(device=0)
+    _stage(one, w, kw)
+    one.set_arrival_limits(4000.0, mx["min_gt"])
+    want1 = one.get_frontier_costs(w.goals[:1], plen[:1], phead[:1], with_fim=with_fim)
+    one.close()
+    _same_records(got["records"], want1["records"])
+    np.testing.assert_array_equal(got["weighted_cost"], want1["weighted_cost"])
+    m.close()
+
+
+@pytest.mark.gpu
+def test_multi_get_frontier_costs_range_error_and_state(fs):
+    """FS_E_RANGE where the reference throws ("Cost out of bounds", FrontierCostsManager.cpp:148-149) comes back through the
+    multi-device call too, and a call before staging names the failing block."""
+    m = fs.MultiScorer(devices=(0, 0))
+    with pytest.raises(fs.FsError) as e:
+        m.get_frontier_costs(np.zeros((4, 3)), np.ones(4), np.zeros(4))
+    assert e.value.code == fs.capi.FS_E_STATE and "block 0" in str(e.value)
+    w = fs.synth.make_workload("C1")
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
+              robot_radius=w.robot_radius, n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+    _stage(m, w, kw)
+    m.set_arrival_limits(1.0, 0.5)                                   # arrival / 1 > 1: the utility leaves [0, 1]
+    n = w.goals.shape[0]
+    plen, phead = _path_columns(n)
+    with pytest.raises(fs.FsError) as e:
+        m.get_frontier_costs(w.goals, plen, phead, w.frontier_size, w.blacklisted)
+    assert e.value.code == fs.capi.FS_E_RANGE
+    m.set_arrival_limits(4000.0, 0.5)                                # and the object is usable afterwards
+    got = m.get_frontier_costs(w.goals, plen, phead, w.frontier_size, w.blacklisted)
+    assert np.array_equal(np.sort(got["order"]), np.arange(n))
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,n_pose", [((0, 0), 600), ((0, 0, 0), 301), ((0, 0, 0, 0), 2)])
+def test_multi_score_fim_equals_one_context(fs, devices, n_pose):
+    w = fs.synth.make_workload("C2", n_cand=n_pose)
+    rng = np.random.default_rng(11)
+    poses = fs.synth.poses_from_yaw(w.goals, rng.uniform(-np.pi, np.pi, n_pose))
+    q = rng.normal(size=(min(5, n_pose), 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses[: q.shape[0], 3:] = q                                      # a few general orientations
+    for angle in (1.0, 4.0):
+        one = fs.FrontierScorer(device=0)
+        one.upload_landmarks(w.landmarks); one.lookup_generate(); one.set_fim_params(14.0, angle)
+        want, want_io = one.score_fim(poses), one.score_fim(poses, info_only=True)
+        one.close()
+        m = fs.MultiScorer(devices=devices)
+        m.upload_landmarks(w.landmarks); m.lookup_generate(); m.set_fim_params(14.0, angle)
+        for _ in range(2):
+            got, got_io = m.score_fim(poses), m.score_fim(poses, info_only=True)
+            for k in ("n_visible", "n_voxels"):
+                np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+            np.testing.assert_array_equal(got_io["n_voxels"], want_io["n_voxels"])
+            for a, b in ((got["info_ref"], want["info_ref"]), (got["trace"], want["trace"]), (got_io["info_ref"], want_io["info_ref"]),
+                         (got["fim21"], want["fim21"])):
+                a, b = a.astype(np.float64), b.astype(np.float64)
+                assert np.all(np.abs(a - b) <= 2e-6 * np.maximum(np.abs(b), 1.0))
+            fin = np.isfinite(want["logdet"])
+            np.testing.assert_array_equal(np.isfinite(got["logdet"]), fin)
+        m.close()
