@@ -57,9 +57,19 @@ public:
     // DEP/src/CostAssigner.cpp:38), "A*PlannerDistance" or "EuclideanDistance"
     void setPlannerMethod(const std::string &method) { planner_method_ = method; }
 
+    // true: the whole cost assignment as ONE device call, fs_multi_get_frontier_costs — the planner runs first (on every live
+    // frontier, as if achievable), then arrival information on every GPU of gpu_devices, the blocks' records gathered device to
+    // device over xGMI onto the first GPU, U1 costs there, one transfer back: the records never visit the host between scoring
+    // and ranking.  Same costs, utilities, arrival information and achievability as the three-step route (the default, which
+    // plans only what arrival information left achievable: FrontierCostsManager.cpp:88-91); what differs is spare planning work.
+    void setFused(bool on) { fused_ = on; }
+
 private:
     // FrontierCostsManager::assignCosts with the arrival-information loop batched on the GPU
     bool assignCosts(std::vector<FrontierPtr> &frontier_list, geometry_msgs::msg::Pose start_pose_w);
+    bool assignCostsFused(std::vector<FrontierPtr> &frontier_list, geometry_msgs::msg::Pose start_pose_w);   // the same through ONE call
+    bool prepareTick(std::vector<FrontierPtr> &frontier_list);   // what both routes do first (:51-72): snapshot, limits, list checks
+    void plan(geometry_msgs::msg::Pose start_pose_w, FrontierPtr &frontier);   // the reference's planner named by planner_method_ (:98-109)
     void snapshotCostmap();                                  // fs_upload_grid under the costmap mutex
     void pushRayParams();                                    // fs_set_ray_params (+ cached arrival limits)
     void restoreArrivalLimits();                             // hands the cached limits back to every device
@@ -73,6 +83,7 @@ private:
     geometry_msgs::msg::Polygon polygon_;
     std::vector<double> polygon_xy_min_max_;
     std::string planner_method_ = "RoadmapPlannerDistance";
+    bool fused_ = false;
 
     // parameters (same keys as the reference)
     double max_camera_depth_, delta_theta_, camera_fov_, robot_radius_;

@@ -140,9 +140,8 @@ bool CostAssignerGPU::updateBoundaryPolygon(geometry_msgs::msg::PolygonStamped &
     return true;
 }
 
-bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geometry_msgs::msg::Pose start_pose_w)
+bool CostAssignerGPU::prepareTick(std::vector<FrontierPtr> &frontier_list)
 {
-    const double dmax = std::numeric_limits<double>::max();
     planner_->reset();                                                           // FrontierCostsManager.cpp:51
     snapshotCostmap();
     if (!arrival_info_limits_set_) {                                             // :52, CostCalculator.cpp:123-191 (cached)
@@ -165,6 +164,79 @@ bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geome
     for (size_t i = 0; i < frontier_list.size(); ++i)                            // :25-45,69-72
         for (size_t j = i + 1; j < frontier_list.size(); ++j)
             if (frontier_list[i] == frontier_list[j]) throw std::runtime_error("Duplicate frontiers found.");
+    return true;
+}
+
+void CostAssignerGPU::plan(geometry_msgs::msg::Pose start_pose_w, FrontierPtr &frontier)
+{
+    auto map_data = std::make_shared<slam_msgs::srv::GetMap::Response>();        // CostAssigner.cpp:37 (left empty there too)
+    if (planner_method_ == "A*PlannerDistance")
+        planner_->setPlanForFrontier(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
+    else if (planner_method_ == "RoadmapPlannerDistance")
+        planner_->setPlanForFrontierRoadmap(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
+    else
+        planner_->setPlanForFrontierEuclidean(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
+}
+
+// assignCosts through ONE device call (fs_multi_get_frontier_costs).  The planner runs FIRST, on every frontier that is not
+// blacklisted and as if achievable; what it decides (a frontier it cannot reach: achievable = false) enters the call as
+// achievable_in, which the arrival step can only clear further — the final flag is the AND of the same conditions in either
+// order, and the path columns of a frontier that ends up unachievable are never read.  (The same construction as
+// FrontierCostsManager::assignCostsFused of the C++ mirror, fit-slam_amd/host/frontier_scoring.hpp, which tests/test_host_mirror.py
+// compares bit for bit with the three-step route.)
+bool CostAssignerGPU::assignCostsFused(std::vector<FrontierPtr> &frontier_list, geometry_msgs::msg::Pose start_pose_w)
+{
+    const double dmax = std::numeric_limits<double>::max();
+    if (!prepareTick(frontier_list)) return false;
+    const int32_t n = static_cast<int32_t>(frontier_list.size());
+    std::vector<double> goal(3 * static_cast<size_t>(n)), plen(n, 0.0), phead(n, 0.0), cost(n), au(n), du(n);
+    std::vector<int32_t> fsize(n);
+    std::vector<uint8_t> black(n, 0), ach_in(n, 1);
+    {
+        std::lock_guard<std::mutex> lock(blacklist_mutex_);
+        for (int32_t i = 0; i < n; ++i) black[i] = frontier_blacklist_.count(frontier_list[i]) > 0 ? 1 : 0;   // :77
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        auto &f = frontier_list[i];
+        const geometry_msgs::msg::Point &g = f->getGoalPoint();
+        goal[3 * i] = g.x; goal[3 * i + 1] = g.y; goal[3 * i + 2] = 0.0;
+        fsize[i] = f->getSize();
+        if (black[i]) continue;
+        plan(start_pose_w, f);                                                   // (the reference's planners return at once for a frontier that is already unachievable)
+        ach_in[i] = f->isAchievable() ? 1 : 0;
+        if (ach_in[i]) { plen[i] = f->getPathLength(); phead[i] = f->getPathHeading(); }
+    }
+    std::vector<fs_record> rec(n);
+    const int rc = fs_multi_get_frontier_costs(scorer_, n, goal.data(), fsize.data(), black.data(), ach_in.data(), plen.data(), phead.data(),
+                                               alpha_, beta_, max_vx_, max_wx_, /*with_fisher_information=*/0,
+                                               rec.data(), cost.data(), au.data(), du.data(), nullptr);
+    if (rc == FS_E_RANGE) throw std::runtime_error("Cost out of bounds");        // :148-149,173-174
+    check(rc, "fs_multi_get_frontier_costs");
+    for (int32_t i = 0; i < n; ++i) {
+        auto &f = frontier_list[i];
+        if (black[i]) {                                                          // :77-86
+            f->setArrivalInformation(0.0); f->setGoalOrientation(0.0); f->setFisherInformation(0.0);
+            f->setPathLength(dmax); f->setPathLengthInM(dmax); f->setWeightedCost(dmax);
+            continue;
+        }
+        f->setArrivalInformation(static_cast<double>(rec[i].arrival));           // CostCalculator.cpp:52 / :112
+        // goal_yaw = maxIndex * delta_theta + fov / 2 in double (:119); 0 where the goal is off the map (:52-54)
+        f->setGoalOrientation(FS_RECORD_STATUS(rec[i].flags) == FS_STATUS_OK ? static_cast<double>(rec[i].argmax) * delta_theta_ + camera_fov_ / 2 : 0.0);
+        const bool achievable = (rec[i].flags & FS_FLAG_ACHIEVABLE) != 0;
+        f->setAchievability(achievable);                                         // :78-82, :114-118
+        if (!achievable) { f->setPathLength(dmax); f->setPathLengthInM(dmax); f->setFisherInformation(0.0); }   // what the skipped plan leaves behind
+        planner_->recomputeNormalizationFactors(f);                              // :118
+        f->setWeightedCost(cost[i]);                                             // :130 / :198
+        f->setCost("arrival_gain_utility", au[i]);                               // :131 / :199
+        f->setCost("distance_utility", du[i]);                                   // :132 / :200
+    }
+    return true;
+}
+
+bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geometry_msgs::msg::Pose start_pose_w)
+{
+    const double dmax = std::numeric_limits<double>::max();
+    if (!prepareTick(frontier_list)) return false;
 
     // ---- arrival information for the whole list: ONE launch instead of the loop of :74-119
     const int32_t n = static_cast<int32_t>(frontier_list.size());
@@ -185,7 +257,6 @@ bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geome
     check(fs_multi_score_arrival(scorer_, n, goal.data(), fsize.data(), black.data(), ach_in.data(), nullptr, arrival.data(),
                                  argmax.data(), yaw.data(), ach.data(), status.data()), "fs_multi_score_arrival");
 
-    auto map_data = std::make_shared<slam_msgs::srv::GetMap::Response>();        // CostAssigner.cpp:37 (left empty there too)
     for (int32_t i = 0; i < n; ++i) {
         auto &frontier = frontier_list[i];
         if (black[i]) {                                                          // :77-86
@@ -201,12 +272,7 @@ bool CostAssignerGPU::assignCosts(std::vector<FrontierPtr> &frontier_list, geome
         frontier->setGoalOrientation(yaw[i]);                                    // :53 / :119
         frontier->setAchievability(ach[i] != 0);                                 // :78-82, :114-118
         // planning stays with the reference (:98-109); it skips frontiers that are not achievable
-        if (planner_method_ == "A*PlannerDistance")
-            planner_->setPlanForFrontier(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
-        else if (planner_method_ == "RoadmapPlannerDistance")
-            planner_->setPlanForFrontierRoadmap(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
-        else
-            planner_->setPlanForFrontierEuclidean(start_pose_w, frontier, map_data, false, planner_allow_unknown_);
+        plan(start_pose_w, frontier);
         planner_->recomputeNormalizationFactors(frontier);                       // :118
     }
 
@@ -243,7 +309,8 @@ bool CostAssignerGPU::getFrontierCosts(std::shared_ptr<GetFrontierCostsRequest> 
     // back from them (weighted cost, path length in metres, arrival information); a failed scoring (empty list, no polygon)
     // only clears `success`.
     setFrontierBlacklist(requestData->prohibited_frontiers);
-    resultData->success = assignCosts(requestData->frontier_list, requestData->start_pose.pose);
+    resultData->success = fused_ ? assignCostsFused(requestData->frontier_list, requestData->start_pose.pose)
+                                 : assignCosts(requestData->frontier_list, requestData->start_pose.pose);
     if (!resultData->success) return false;
     const std::vector<FrontierPtr> &scored = requestData->frontier_list;
     resultData->frontier_list.assign(scored.begin(), scored.end());
