@@ -127,6 +127,9 @@ struct fs_ctx {
     DevBuf<uint8_t> d_cells;                        // dense row-major image (FsGridDev)
     DevBuf<uint32_t> d_cls;                         // 2-bit class image, cut lazily for cls_ranges (long rays only)
     bool have_cls = false;
+    DevBuf<uint32_t> d_cls_table, d_cls_pool;       // "ray.layout" 3: brick table + pool of distinct bricks (the sparse form of d_cls)
+    bool have_sparse = false;
+    uint64_t sparse_bricks = 0, sparse_pool_bricks = 0;
     int32_t cls_ranges[4] = {0, 0, 0, 0};
     int32_t nx = 0, ny = 0, nz = 0;
     double origin[3] = {0, 0, 0};
@@ -220,7 +223,7 @@ struct fs_ctx {
     bool opt_costmap = true;       // the spatial sort puts the blocks that were expensive in the previous call first ("sort.costmap")
     const uint32_t *sort_keys = nullptr;   // this call's sort keys / the cost map inside sort_scratch (nullptr: list not sorted)
     uint32_t *sort_costmap = nullptr;
-    int opt_layout = 0;            // "ray.layout": 0 by ray length, 1 row-major byte walk, 2 class-image walk
+    int opt_layout = 0;            // "ray.layout": 0 by ray length, 1 row-major byte walk, 2 class-image walk, 3 sparse class image (experiment)
 
     // launch graphs of the small host-buffer calls ("graph" option; off while kernel timing is on)
     bool opt_zero_copy = true;     // "zerocopy": small host-buffer calls read / write the mapped page-locked buffers in place
@@ -539,7 +542,7 @@ bool use_class_walk(const fs_ctx *c, double max_length_cells)
     // pad to 2^32 class cells or more — 4 x 4 x 2^26 does; such a grid keeps the byte walk)
     const uint64_t padded_cells = stride * (uint64_t)((c->nz + 7) >> 3);
     if (c->opt_layout == 1 || stride >= (1ull << 24) || padded_cells >= (1ull << 32)) return false;
-    if (c->opt_layout == 2) return true;
+    if (c->opt_layout >= 2) return true;
     return c->nz > 1 || max_length_cells >= FS_CLASS_WALK_FROM;
 }
 
@@ -547,13 +550,47 @@ FsGridDev grid_dev(const fs_ctx *c)
 {
     const uint32_t bx = (uint32_t)(c->nx + 7) >> 3, by = (uint32_t)(c->ny + 7) >> 3, bz = (uint32_t)(c->nz + 7) >> 3;
     return FsGridDev{c->d_cells.p, c->nx, c->ny, c->nz, c->origin[0], c->origin[1], c->origin[2], c->res, c->d_counters.p + 29,
-                     c->have_cls ? c->d_cls.p : nullptr, {512u - 8u, 512u * bx - 64u, 512u * bx * by - 512u}, 512u * bx * by * bz};
+                     c->have_cls ? c->d_cls.p : nullptr, {512u - 8u, 512u * bx - 64u, 512u * bx * by - 512u}, 512u * bx * by * bz, nullptr};
 }
 
 // every upload path ends here: images derived from the grid are cut again on next use
 int retile_grid(fs_ctx *c, int32_t, int32_t, int32_t)
 {
     c->have_cls = false;
+    c->have_sparse = false;
+    return FS_OK;
+}
+
+// The sparse form of the class image: the dense one (already cut on the device) is read back, every brick whose 512 cells are
+// of ONE class points at the shared uniform brick of that class (pool slots 0..3), every other brick gets a slot of its own.
+// A staging-time pass on the host — this is the experiment's set-up, not a path anybody waits for per tick.
+int build_sparse_class_image(fs_ctx *c)
+{
+    const uint64_t bricks = (uint64_t)((c->nx + 7) >> 3) * (uint64_t)((c->ny + 7) >> 3) * (uint64_t)((c->nz + 7) >> 3);
+    std::vector<uint32_t> dense(bricks * 32), table(bricks), pool;
+    FS_HIP(c, hipMemcpyAsync(dense.data(), c->d_cls.p, dense.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    static const uint32_t uniform[4] = {0x00000000u, 0x55555555u, 0xAAAAAAAAu, 0xFFFFFFFFu};
+    pool.reserve(4 * 32 + (size_t)(bricks / 2) * 32);
+    for (int k = 0; k < 4; ++k) pool.insert(pool.end(), 32, uniform[k]);
+    for (uint64_t b = 0; b < bricks; ++b) {
+        const uint32_t *w = &dense[b * 32];
+        bool same = true;
+        for (int i = 1; i < 32 && same; ++i) same = w[i] == w[0];
+        int k = -1;
+        if (same) for (int u = 0; u < 4; ++u) if (w[0] == uniform[u]) k = u;
+        if (k >= 0) { table[b] = (uint32_t)k; continue; }
+        table[b] = (uint32_t)(pool.size() / 32);
+        pool.insert(pool.end(), w, w + 32);
+    }
+    if (pool.size() / 32 >= (1ull << 23)) return fail(c, FS_E_INVALID, "sparse class image: more than 2^23 distinct bricks");   // (slot << 9 must stay in 32 bits)
+    FS_HIP(c, c->d_cls_table.ensure(table.size())); FS_HIP(c, c->d_cls_pool.ensure(pool.size()));
+    FS_HIP(c, hipMemcpyAsync(c->d_cls_table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipMemcpyAsync(c->d_cls_pool.p, pool.data(), pool.size() * 4, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));
+    c->sparse_bricks = bricks; c->sparse_pool_bricks = pool.size() / 32;
+    c->have_sparse = true;
+    ++c->epoch;
     return FS_OK;
 }
 
@@ -585,10 +622,17 @@ int fill_ray_args(fs_ctx *c, FsRayArgs &a, bool class_ok = true)
                 return fail(c, FS_E_HIP, "could not stage the class image of the grid");
             std::memcpy(c->cls_ranges, want, sizeof want);
             c->have_cls = true;
+            c->have_sparse = false;
             ++c->epoch;
         }
         a.grid = grid_dev(c);
         a.layout = 1;
+        if (c->opt_layout == 3) {
+            if (!c->have_sparse) { const int rc = build_sparse_class_image(c); if (rc) return rc; }
+            a.grid.cls = c->d_cls_pool.p;
+            a.grid.cls_table = c->d_cls_table.p;
+            a.layout = 2;
+        }
     }
     a.obst_min = p.obst_min; a.obst_max = p.obst_max; a.trace_min = p.trace_min; a.trace_max = p.trace_max;
     a.clamp = 1;
@@ -733,7 +777,7 @@ void fs_ctx_destroy(fs_ctx *c)
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto &g : c->graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
     c->d_out.release();
-    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_cls.release();
+    c->d_dir.release(); c->d_yawR.release(); c->d_cells.release(); c->d_cls.release(); c->d_cls_table.release(); c->d_cls_pool.release();
     c->d_lx.release(); c->d_ly.release(); c->d_lz.release(); c->d_spheres.release(); c->d_counters.release();
     c->d_table.release(); c->d_factor.release(); c->d_gtable.release();
     c->d_kf_check.release(); c->d_kf_tri.release(); c->d_kf_off.release(); c->d_kf_flagged.release(); c->d_kf_cells.release();
@@ -1401,7 +1445,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 2) { c->opt_layout = (int)value; return FS_OK; }
+    if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 3) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.headroom") == 0 && value >= 8 && value <= 64) { c->opt_headroom = (int)value; return FS_OK; }
@@ -1410,6 +1454,8 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
 
 int fs_get_counter(fs_ctx *c, int which, int64_t *value, int reset)
 {
+    // host-side figures of the sparse class image ("ray.layout" 3): 1000 bricks of the grid, 1001 bricks its pool holds
+    if (c && value && (which == 1000 || which == 1001)) { *value = (int64_t)(which == 1000 ? c->sparse_bricks : c->sparse_pool_bricks); return FS_OK; }
     if (!c || !value || which < 0 || which >= FS_N_COUNTERS) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
     *value = 0;

@@ -38,6 +38,10 @@ struct FsGridDev {
     const uint32_t *cls;       // class image, or nullptr while it has not been cut
     uint32_t cls_m[3];         // 512 - 8, 512 * bricks_x - 64, 512 * bricks_x * bricks_y - 512  (brick stride of the axis minus 8 << l)
     uint32_t cls_cells;        // cells the image holds (padded to whole bricks)
+    // SPARSE form of the class image ("ray.layout" 3; BASELINE.json configs[4] "sparse-hashed voxel grid"): `cls` is then a POOL of
+    // 128-B bricks and cls_table[brick-linear index] the slot of the brick's content in it — slots 0..3 are the four uniform
+    // bricks (every cell of one class: all-unknown, all-free, ...), shared by every brick of that content.  nullptr: dense.
+    const uint32_t *cls_table;
 };
 
 // dwords of the class image of an nx x ny x nz grid, and the kernel that fills it (bit 0: cost in [trace_min, trace_max], bit 1: in [obst_min, obst_max])
@@ -55,7 +59,7 @@ struct FsRayArgs {
     uint32_t max_length;       // (unsigned)(max_camera_depth / resolution), CostCalculator.cpp:28
     int32_t obst_min, obst_max, trace_min, trace_max;
     int32_t clamp;             // CostCalculator.cpp:47-48 (1) or setMaxArrivalInformation (0)
-    int32_t layout;            // 0: row-major byte image (WalkLinear), 1: class image (WalkClass)
+    int32_t layout;            // 0: row-major byte image (WalkLinear), 1: class image (WalkClass), 2: sparse class image (WalkSparse)
     double lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // folded clamp bounds: max(poly_min, origin), min(poly_max, origin + sizeInMeters)
     double footprint_radius;   // ceil(robot_radius / resolution)
     double delta_theta, half_fov;

@@ -92,6 +92,11 @@ struct WalkClass {
     uint32_t end;
 };
 
+// WalkSparse — WalkClass over the SPARSE class image (FsGridDev::cls_table): the same coordinates and steps, one more
+// dependent load per cell (the brick's slot in the pool).  Built as the one measurement of BASELINE.json configs[4]'s "sparse"
+// (profiles/EXPERIMENTS.md holds the outcome).
+struct WalkSparse : WalkClass {};
+
 // one minor axis of a walk: e += |d_minor|; if (e >= |d_major|) { v += sign; e -= |d_major|; } in five instructions —
 // the subtraction's borrow IS the comparison (v_sub_co_u32), the smaller of e and e - |d_major| (unsigned wrap) is the new
 // error term.  (The compiler spends a sixth on a separate compare.)
@@ -122,6 +127,8 @@ __device__ __forceinline__ void walk_step(WalkClass &w)
     minor_step(w.c, w.ec, w.adc, w.abs_da, w.sgc);
 }
 
+__device__ __forceinline__ void walk_step(WalkSparse &w) { walk_step(static_cast<WalkClass &>(w)); }
+
 // The cell under the walk.  Both end points are on the map (worldToMap succeeded) and a Bresenham walk between two
 // cells never leaves their bounding box — each axis takes at most |d_axis| steps towards the end point — so every
 // visit, including the speculative ones (they stay within `visits`), is inside the grid.
@@ -148,6 +155,22 @@ __device__ __forceinline__ uint32_t walk_class(const FsGridDev &g, const WalkCla
 #endif
     const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(g.cls) + ((A >> 2) & ~3u));
     return __builtin_amdgcn_ubfe(word, A << 1, 2u);            // v_bfe_u32 takes the offset modulo 32: field A & 15
+}
+
+// ... through the brick table: A >> 9 is the brick (brick-linear order), A & 511 the cell inside it
+__device__ __forceinline__ uint32_t walk_class(const FsGridDev &g, const WalkSparse &w)
+{
+    uint32_t A = w.a + w.b + w.c;
+    A = (uint32_t)__umul24(w.c >> w.hc, w.mc) + A;
+    A = (uint32_t)__umul24(w.b >> w.hb, w.mb) + A;
+    A = (uint32_t)__umul24(w.a >> w.ha, w.ma) + A;
+#ifdef FS_RAY_BOUNDS
+    if (A >= g.cls_cells) { atomicMax(g.dbg, 6ull); return 0u; }
+#endif
+    const uint32_t slot = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(g.cls_table) + ((A >> 9) << 2));
+    const uint32_t B = (slot << 9) | (A & 511u);
+    const uint32_t word = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(g.cls) + ((B >> 2) & ~3u));
+    return __builtin_amdgcn_ubfe(word, A << 1, 2u);
 }
 
 // getTracedCells from the two map cells on (Helpers.cpp:46-94): `(unsigned)(scale * abs_da)` visits with
@@ -217,6 +240,12 @@ __device__ __forceinline__ void walk_init(WalkClass &w, const FsGridDev &g, uint
     }
     w.eb = w.ec = (int)(w.abs_da / 2);
     w.end = walk_visits(dx, dy, dz, w.abs_da, max_length);
+}
+
+__device__ __forceinline__ void walk_init(WalkSparse &w, const FsGridDev &g, uint32_t x0, uint32_t y0, uint32_t z0,
+                                          uint32_t x1, uint32_t y1, uint32_t z1, double max_length)
+{
+    walk_init(static_cast<WalkClass &>(w), g, x0, y0, z0, x1, y1, z1, max_length);
 }
 
 // The start cell is the same for every ray of a fan: its worldToMap (three fp64 divisions) is done once per candidate;
@@ -297,7 +326,8 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
 // The visitor over the class image (the classes were cut with this launch's ranges: fs_capi.hip keeps them in step): bit 0
 // counts while no earlier cell of the ray carried bit 1 (Helpers.hpp:64-71 — the traced test comes before hit_obstacle is set,
 // so a cell in both ranges still counts).
-__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkClass w)
+template <typename W>
+__device__ __forceinline__ int ray_march_classes(const FsRayArgs &a, W w)
 {
     int count = 0;
     uint32_t visits = w.end + 1;
@@ -337,6 +367,9 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkClass w)
     }
     return count;
 }
+
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkClass w) { return ray_march_classes(a, w); }
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkSparse w) { return ray_march_classes(a, w); }
 
 // Every wave of the kernel below works on LDS of its own (per-yaw sums, tile, descriptors): what it wrote must be visible to
 // its own later reads — which the LDS guarantees per wave, in program order — so the points where that matters need the
@@ -541,7 +574,8 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
     int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
     if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
-    if (a.layout == 1) hipLaunchKernelGGL(fs_raymarch_kernel<WalkClass>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    if (a.layout == 2) hipLaunchKernelGGL(fs_raymarch_kernel<WalkSparse>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
+    else if (a.layout == 1) hipLaunchKernelGGL(fs_raymarch_kernel<WalkClass>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else hipLaunchKernelGGL(fs_raymarch_kernel<WalkLinear>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();
 }

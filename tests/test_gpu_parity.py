@@ -538,7 +538,7 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
             _setup_scorer(scorer, w)
             mx_o = oracle.max_arrival_information(G, P)
             want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx_o["min_gt"], n_threads=8)
-            for layout in (1, 2, 0):                               # 1 row-major byte image, 2 class image, 0 chosen by ray length
+            for layout in (1, 2, 3, 0):                            # 1 row-major byte image, 2 class image, 3 sparse class image (brick table + pool), 0 chosen by ray length
                 scorer.set_option("ray.layout", layout)
                 assert scorer.max_arrival() == mx_o
                 _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
