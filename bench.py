@@ -497,7 +497,7 @@ def other_visibility(args, sc, w, n_local, d_goal, d_fsize, d_black, d_rec, dev,
                                  "m_tested_per_pose": sc.get_counter(0, reset=True) / (reps * n_local),
                                  "multi_pass_poses_per_call": (sc.get_counter(4) - mp0) / reps,
                                  "hbm_table_poses_per_call": (sc.get_counter(5) - t30) / reps,
-                                 "learnt_voxels_per_landmark_scanned": sc.get_counter(12) / 256.0,
+                                 "learnt_voxels_per_landmark_scanned": sc.get_counter(13) / 256.0,
                                  "fim_worker": "INFO_ONLY (no 6x6 sums, exact table-box cull), cone " + ("off" if angle >= np.pi else "1.0 rad"),
                                  "note": "fs_score_fim(n = all poses of the step) with NULL for every column but info_ref / n_voxels — what FisherInformationManager::isPoseSafe reads; host poses in, PCIe both ways included in ms_per_call"}
         if args.cpu_seconds > 0:

@@ -458,7 +458,7 @@ static void reset_voxel_ratio(fs_ctx *c)
 {
     if (!c->d_counters.p) return;
     (void)hipSetDevice(c->device);                         // (callers on the table path have not bound the device yet)
-    (void)hipMemsetAsync(c->d_counters.p + 12, 0, sizeof(unsigned long long), c->stream);
+    (void)hipMemsetAsync(c->d_counters.p + 12, 0, 2 * sizeof(unsigned long long), c->stream);   // both ratios (FsFimArgs::ratio_slot)
 }
 
 // Dense re-indexing of the record list by the integer voxel lattice (what loadLookupTable's

@@ -519,7 +519,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
     // Pass prediction: distinct voxels <= skip32/32 of the landmarks scanned.  FsFimArgs::skip32 (13/32: p99 0.40 on C3) is the
     // cap for a cloud nothing is known about; once calls on this cloud have been finished, the largest ratio any candidate
-    // showed (counters[12], in 1/256, kept by the finish kernel; reset with the cloud, the table and the visibility volume)
+    // showed (counters[ratio_slot] = 12 or 13 by what the worker hashes from, in 1/256, kept by the finish kernel; reset with the cloud, the table and the visibility volume)
     // times 5/4 plus 1/32 takes over when it is smaller (only candidates with >= 16 k landmarks scanned count) — a dense slab seen from inside (REF2D) holds many landmarks per voxel
     // and was being scored in two passes for nothing.  A candidate that outgrows the prediction overflows its table, goes to
     // the HBM tier (correct, slower) and raises the ratio for the next call.
@@ -529,7 +529,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // fixed cap alone for runs that must reproduce those bits.
     int skip32_eff = a.skip32;
     {
-        const uint32_t seen = a.learn ? (uint32_t)a.counters[12] : 0u;
+        const uint32_t seen = a.learn ? (uint32_t)a.counters[a.ratio_slot] : 0u;
         if (seen != 0u) {
             const int s = (int)((seen * (uint32_t)a.headroom + 255u) / 256u) + 1;      // headroom / 32 (5/4 by default) of the ratio, + 1/32
             skip32_eff = s < skip32_eff ? (s > 2 ? s : 2) : skip32_eff;
@@ -856,7 +856,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         }
         if (tid == 0) {
             // tier that must re-score the candidate (0: done) | chunks scanned per pass << 4 (the finish kernel's voxel ratio)
-            a.overflow[c] = (failed ? fail_code : 0u) | ((uint32_t)(wg_hash < (1 << 27) ? wg_hash : (1 << 27)) << 4);
+            // (the HBM tier keeps the count the LDS worker filed with the hand-over — chunks that can be HASHED, which for the box-culling
+            // workers is fewer than the chunks in range this worker scans: the finish kernel's ratio must stay relative to the base
+            // the next call's LDS worker predicts with, or a pose that overflowed teaches half its ratio and overflows again)
+            uint32_t base = (uint32_t)(wg_hash < (1 << 27) ? wg_hash : (1 << 27));
+            if (GLOBAL_TABLE) base = a.overflow[c] >> 4;
+            a.overflow[c] = (failed ? fail_code : 0u) | (base << 4);
             const uint32_t lm_tested = SUMS_AT_TEST ? (uint32_t)wg_tested * 64u + (uint32_t)wg_hash * 64u * (uint32_t)(n_parts - 1)   // first pass + the later ones
                                                     : (uint32_t)wg_tested * 64u * (uint32_t)n_parts;
             if (!skip_tier && wg_tested > 0) atomicAdd(&a.tested[c], lm_tested);   // landmarks tested (M_tested), summed by the finish kernel
@@ -944,7 +949,7 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
             }
         }
         for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(r, d); r = o > r ? o : r; }
-        if ((threadIdx.x & 63) == 0 && r > (uint32_t)a.counters[12]) atomicMax(&a.counters[12], (unsigned long long)r);
+        if ((threadIdx.x & 63) == 0 && r > (uint32_t)a.counters[a.ratio_slot]) atomicMax(&a.counters[a.ratio_slot], (unsigned long long)r);
     }
     if (c == 0) {                                            // per-call tier counters -> running totals
         a.counters[4] += a.counters[1];
@@ -1098,10 +1103,20 @@ hipError_t launch_overflow(FsFimArgs &a, int pool, hipStream_t s)
 
 }  // namespace
 
+// which learnt voxel ratio a call works with (FsFimArgs::ratio_slot): 13 where the LDS worker that runs hashes from the chunks that
+// can meet the table's box (cone off: SUMS_AT_TEST; INFO_ONLY), 12 where it hashes from everything in range and cone
+static int ratio_slot_of(const FsFimArgs &a)
+{
+    const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
+    const bool special = a.table_full && cone != FS_CONE_ANY;
+    return (cone == FS_CONE_OFF || (special && a.info_only)) ? 13 : 12;
+}
+
 hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
 {
     if (a0.n <= 0 || a0.cand_count <= 0) return hipSuccess;
     FsFimArgs a = a0;
+    a.ratio_slot = ratio_slot_of(a);
     const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
     // The specialised workers exist for finite tables (every generated one) and the two common cone modes; anything else runs the
     // general worker, which computes a superset (the finish kernel then hands out what was asked for).
@@ -1124,12 +1139,15 @@ hipError_t fs_launch_fim_overflow(const FsFimArgs &a0, int pool, hipStream_t s)
 {
     if (a0.n <= 0) return hipSuccess;
     FsFimArgs a = a0;
+    a.ratio_slot = ratio_slot_of(a);
     return a.table_full ? launch_overflow<true>(a, pool, s) : launch_overflow<false>(a, pool, s);
 }
 
-hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s)
+hipError_t fs_launch_fim_finish(const FsFimArgs &a0, hipStream_t s)
 {
-    if (a.n <= 0) return hipSuccess;
+    if (a0.n <= 0) return hipSuccess;
+    FsFimArgs a = a0;
+    a.ratio_slot = ratio_slot_of(a);
     hipLaunchKernelGGL(fs_fim_finish_kernel, dim3((a.n + 63) / 64), dim3(64), 0, s, a);      // one wave per block: 20 k candidates spread over all CUs
     return hipGetLastError();
 }

@@ -163,7 +163,12 @@ struct FsFimArgs {
     // specialised workers (fs_fim.hip): info_only — the call reads info_ref / n_voxels only (fs_score_fim with NULL for the other
     // columns: what isPoseSafe needs); yaw_only — every pose record is a rotation about Z (checked on the host)
     int32_t info_only, yaw_only;
-    int32_t learn;                    // 1: predict scoring passes with the voxel ratio learnt from finished calls (counters[12]); 0: skip32 only
+    int32_t learn;                    // 1: predict scoring passes with the voxel ratio learnt from finished calls (counters[ratio_slot]); 0: skip32 only
+    // which learnt ratio this call predicts with and feeds: 12 — distinct voxels per landmark of the chunks in RANGE AND CONE (what the
+    // cone workers hash from); 13 — per landmark of the chunks that can also meet the table's BOX (what the INFO_ONLY and the cone-off
+    // workers hash from).  Two bases, two ratios: a pose shows up to twice as many voxels per landmark of the second kind.
+    // Set by the launchers (fs_fim.hip), not by the caller.
+    int32_t ratio_slot;
     float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;
@@ -190,7 +195,7 @@ struct FsFimArgs {
     const double *rec_yaw;
     const uint8_t *rec_achievable;
     unsigned long long *counters;   // [16]: 0 landmarks tested; per call 1 multi-pass candidates, 2 handed to the HBM tier, 3 unresolved; 4..6 their running totals; 8 / 9 work-list cursors of the LDS / HBM tier;
-                                    // 10 / 11 landmark tests / candidates since the last spatial sort (its cost-map mean)
+                                    // 10 / 11 landmark tests / candidates since the last spatial sort (its cost-map mean); 12 / 13 learnt voxel ratios (ratio_slot)
     // hash tables
     int32_t hash_bits;         // LDS tier (512-thread workgroups)
     int32_t skip32;            // pass-count prediction: distinct voxels <= skip32/32 of the landmarks scanned

@@ -48,7 +48,7 @@ def main():
                 base = r["n_voxels"].copy()
             out = dict(info_only=info_only, skip32=skip32, headroom=headroom, fim_kernel_ms=k1 / n1, hbm_tier_ms=k2 / n1,
                        m_tested=sc.get_counter(0, reset=True) / (reps * n), multi_pass=(sc.get_counter(4) - mp0) / reps,
-                       hbm_poses=(sc.get_counter(5) - h0) / reps, learnt=sc.get_counter(12) / 256.0,
+                       hbm_poses=(sc.get_counter(5) - h0) / reps, learnt=max(sc.get_counter(12), sc.get_counter(13)) / 256.0,
                        n_voxels_same=bool(np.array_equal(r["n_voxels"], base)))
             print(json.dumps(out), flush=True)
     q = np.percentile(base, [50, 90, 99, 100])
