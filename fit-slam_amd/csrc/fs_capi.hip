@@ -186,7 +186,8 @@ struct fs_ctx {
     DevBuf<int32_t> d_fsize, d_arrival, d_argmax, d_status, d_nvis, d_nvox, d_raycounts, d_order, d_err;
     DevBuf<uint8_t> d_black, d_achin, d_ach;
     DevBuf<float> d_info, d_trace, d_logdet, d_fim21, d_Rt;
-    DevBuf<uint32_t> d_overflow, d_tested;
+    DevBuf<uint32_t> d_overflow, d_tested, d_split_flags;
+    int opt_split = 3;             // "fim.split": log2 of the workgroups ONE info-only pose is spread over when a call has few poses (0: off)
     DevBuf<int32_t> d_flagged;
     size_t tested_zeroed = 0;
     DevBuf<fs_record> d_records;
@@ -789,7 +790,7 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_nvis.release(); c->d_nvox.release(); c->d_raycounts.release(); c->d_order.release(); c->d_err.release();
     c->d_black.release(); c->d_achin.release(); c->d_ach.release();
     c->d_info.release(); c->d_trace.release(); c->d_logdet.release(); c->d_fim21.release(); c->d_Rt.release();
-    c->d_overflow.release(); c->d_tested.release(); c->d_flagged.release(); c->d_records.release();
+    c->d_overflow.release(); c->d_tested.release(); c->d_split_flags.release(); c->d_flagged.release(); c->d_records.release();
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->sort_scratch) (void)hipFree(c->sort_scratch);
     c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release();
@@ -1445,6 +1446,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "fim.split") == 0 && value >= 0 && value <= 5) { c->opt_split = (int)value; ++c->epoch; return FS_OK; }
     if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 3) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }
@@ -1620,6 +1622,24 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
     // isPoseSafe reads the scalar alone (FIP/src/fisher_information/FisherInfoManager.cpp:83-100): a call that asks for nothing
     // but info_ref (and, at no cost, n_voxels) takes the worker without the 6x6 sums and with the exact table-box cull
     a.info_only = (c->opt_special && !fim21 && !trace && !logdet && !n_visible) ? 1 : 0;
+    // A call with few poses leaves most of the chip idle — ONE pose is one of 512 workgroup slots, and the reference's real call is
+    // one pose per tick (FisherInfoBTPlugin.cpp:24-57): spread each pose over W = 2^shift workgroups by voxel slab (fs_fim.hip, SPLIT),
+    // as long as all n * W items are resident at once.  Same multiset of (voxel value, rank) terms; the partial sums are added in the
+    // finish kernel.
+    a.split_shift = 0; a.split_flags = nullptr;
+    if (a.info_only && c->opt_split > 0 && fs_fim_can_split(a)) {
+        int shift = c->opt_split;
+        while (shift > 0 && (nn << shift) > 256) --shift;
+        if (shift > 0) {
+            if (c->d_split_flags.cap < nn) {
+                FS_HIP(c, c->d_split_flags.ensure(nn));
+                FS_HIP(c, hipMemsetAsync(c->d_split_flags.p, 0, c->d_split_flags.cap * sizeof(uint32_t), c->stream));
+            }
+            rc = ensure_candidate_scratch(c, nn << shift, false);
+            if (rc) return rc;
+            a.split_shift = shift; a.split_flags = c->d_split_flags.p;
+        }
+    }
     // (the box cull leaves only chunks that can hold voxels of the table, so a pose shows more distinct voxels per landmark
     // scanned than the 13/32 the general worker caps its pass prediction at — C3, cone off: up to 0.5; an extra pass costs a
     // re-test of the landmarks, an overflow the HBM tier)
@@ -1648,7 +1668,7 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
                 o += (cols[k].bytes + 15) & ~(size_t)15;
             }
         }
-        int r = run_fim_tier1(c, a, nullptr, 0, a.n);
+        int r = run_fim_tier1(c, a, nullptr, 0, a.n << a.split_shift);      // (split: n * W work items)
         if (r) return r;
         r = run_fim_rest(c, a);
         if (r) return r;
@@ -1662,7 +1682,7 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
         return FS_OK;
     };
     // ONE pose is isPoseSafe's call: its launch sequence is captured (per number of poses up to 4, requested columns, cull mode)
-    if (n <= 4) rc = run_maybe_graphed(c, (2ull << 40) | ((uint64_t)n << 8) | (col_mask << 1) | (uint64_t)(a.cull ? 1 : 0) | (in_place ? 128u : 0u), enqueue);
+    if (n <= 4) rc = run_maybe_graphed(c, (2ull << 40) | ((uint64_t)a.split_shift << 32) | ((uint64_t)n << 8) | (col_mask << 1) | (uint64_t)(a.cull ? 1 : 0) | (in_place ? 128u : 0u), enqueue);
     else rc = enqueue();
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     size_t off = 0;

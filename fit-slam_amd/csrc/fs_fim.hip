@@ -352,9 +352,17 @@ struct FimWork {
 // R8 = 1 exactly, hence fma(R3, dy, R6 * dz) is R3 * dy and pz is dz bit for bit (up to the sign of a zero, which no
 // consumer sees) — the transform takes 7 instructions instead of 12.  The host checks the zeros before selecting it.
 enum { FS_CONE_OFF = 0, FS_CONE_NARROW = 1, FS_CONE_ANY = 2 };
-template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY>
+// SPLIT: ONE pose over W = 2^split_shift workgroups (the reference's real call is one pose per tick, FisherInfoBTPlugin.cpp:24-57 — one
+// of 512 workgroup slots).  A work item is then (pose, w): item id = pose * W + w.  Workgroup w tests every accepted chunk, like a
+// scoring pass, but hashes only the landmarks whose voxel belongs to it — voxel_part over W x n_parts parts, the low bits of the
+// part id being w — so whole voxels stay in one workgroup (a voxel's ranks must be counted in one table), every landmark is scored
+// exactly once, and each workgroup needs 1/W of the table.  Partial sums go to slot pose * W + w; the finish kernel adds them.
+template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY, bool SPLIT = false>
 __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits)
 {
+    static_assert(!SPLIT || (INFO_ONLY && !GLOBAL_TABLE), "the split worker exists for the info-only LDS tier");
+    const int split_shift = SPLIT ? a.split_shift : 0;
+    const int split_w_mask = (1 << split_shift) - 1;
     constexpr uint32_t fail_code = GLOBAL_TABLE ? 3u : 2u;
     // With the cone off, roughly half of what is visible (everything within range) lies outside the lookup table's box — behind the
     // camera, mostly — and only feeds the 6x6 sums and the visible count.  SUMS_AT_TEST adds those two for EVERY visible landmark
@@ -384,7 +392,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     auto item = [&](int i) -> int {
         if (i >= work.count) return -1;
         const int cid = work.list ? work.list[work.lo + i] : work.lo + i;
-        return FS_BOUND(cid >= 0 && cid < a.n, 2) ? cid : -1;
+        return FS_BOUND(cid >= 0 && cid < (a.n << split_shift), 2) ? cid : -1;     // (SPLIT: an item id, pose * W + w)
     };
     auto fetch = [&]() -> int {                                    // thread 0 only
         return item((int)atomicAdd(work.counter, 1ull) + preassigned);
@@ -548,7 +556,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // with the factor table and the resident spheres)
     const int first_item = GLOBAL_TABLE ? -1 : __builtin_amdgcn_readfirstlane(item((int)blockIdx.x));
     PoseLoad first_pose;
-    if (!GLOBAL_TABLE && first_item >= 0) first_pose = load_pose(first_item);
+    if (!GLOBAL_TABLE && first_item >= 0) first_pose = load_pose(first_item >> split_shift);
     for (int i = tid; i < FS_FACTOR_N; i += THREADS) lfac[i] = a.factor[i];
     __syncthreads();
     // values read back from LDS flags are the same in every lane; readfirstlane tells the compiler so, which keeps the
@@ -562,7 +570,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #pragma unroll
     for (int i = 0; i < 3; ++i) tn[i] = 0.f;
     if (cur >= 0) {
-        if (GLOBAL_TABLE) first_pose = load_pose(cur);
+        if (GLOBAL_TABLE) first_pose = load_pose(cur >> split_shift);
         cur_key = pose_word(first_pose, 13);
         cull(first_pose, 0, Rn, tn);
     }
@@ -573,7 +581,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     unsigned long long tprev = __builtin_readcyclecounter();
 #endif
     while (cur >= 0) {
-        const int c = cur;
+        const int c = cur >> split_shift;                           // the pose; SPLIT: cur is the item id
+        const int split_w = cur & split_w_mask;
 #ifdef FS_FIM_SCHEDULE
         // development build: when did this workgroup start the candidate and how long did it take (plain stores by one
         // thread, no atomics: the schedule of the persistent grid is read back through fs_get_counter)
@@ -611,7 +620,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (!GLOBAL_TABLE) {
             // = landmarks scanned * skip32 / 32, in 32 bits (beyond 2^20 accepted chunks the answer is the HBM tier anyway)
             const uint32_t scanned2 = (uint32_t)(wg_hash < (1 << 20) ? wg_hash : (1 << 20)) * 2u;
-            const uint32_t predicted = scanned2 * (uint32_t)skip32_eff;
+            const uint32_t predicted = (scanned2 * (uint32_t)skip32_eff) >> split_shift;      // (SPLIT: this workgroup's 1/W of the voxels)
             const int k = (predicted > capacity ? 1 : 0) + (predicted > 2u * capacity ? 1 : 0) + (predicted > 4u * capacity ? 1 : 0) +
                           (predicted > 8u * capacity ? 1 : 0);
             n_parts = 1 << k;                                                         // 1, 2, 4, 8 passes
@@ -620,7 +629,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         int bits = tier_bits;
         if (!GLOBAL_TABLE && n_parts == 1) {
             // smallest table with at least as many slots as landmarks scanned, between 2^10 and the tier's size
-            const uint32_t want = (uint32_t)wg_hash * 64u;       // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
+            const uint32_t want = ((uint32_t)wg_hash * 64u) >> split_shift;       // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
             const int need = want > 1024u ? 32 - __builtin_clz(want - 1u) : 10;
             bits = need < tier_bits ? need : tier_bits;
         }
@@ -650,7 +659,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         const int nxt = __builtin_amdgcn_readfirstlane(sh_next[buf ^ 1]);
         PoseLoad next_pose;                                        // in flight during this candidate's scoring loop
         uint32_t next_key = 0u;
-        if (nxt >= 0) next_pose = load_pose(nxt);
+        if (nxt >= 0) next_pose = load_pose(nxt >> split_shift);
         if (tid == 0) sh_overflow[buf ^ 1] = 0;                    // flag of the candidate after this one
         // (the flag is read and written with workgroup-scope atomics on the LDS array itself: a `volatile int *` into it
         // decays to a generic pointer, and FLAT accesses count on vmcnt — every read drained the landmark prefetch)
@@ -730,7 +739,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     else if (a.cone_mode == 2) v = v && ((px >= 0.0f) || (px2 <= a.cos2 * n2));
                     m3 = v ? 0.0f : -1.0f;
                 }
-                if (__builtin_expect(n_parts > 1, 0)) m3 = (voxel_part(a, true, px, n_parts) == part) ? m3 : -1.0f;   // wave-uniform branch (out of line: a taken branch costs a wave its instruction buffer); every lane evaluates
+                if (SPLIT) m3 = (voxel_part(a, true, px, n_parts << split_shift) == ((part << split_shift) | split_w)) ? m3 : -1.0f;
+                else if (__builtin_expect(n_parts > 1, 0)) m3 = (voxel_part(a, true, px, n_parts) == part) ? m3 : -1.0f;   // wave-uniform branch (out of line: a taken branch costs a wave its instruction buffer); every lane evaluates
                 const bool vis = m3 >= 0.0f;
                 // ---- 3. compact
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(vis);
@@ -852,7 +862,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) x += (double)part[w];
             const int q_out = (INFO_ONLY && qi > 0) ? FS_NACC - NRED + qi : qi;     // info stays sum 0, the two counts sums 16 and 17
-            if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[(size_t)c * FS_NACC + q_out] = x;
+            // (SPLIT: the partial sums of item `cur`; the HBM tier of a split call writes the whole pose into the pose's first slot)
+            const size_t slot = SPLIT ? (size_t)cur : ((size_t)c << (GLOBAL_TABLE ? a.split_shift : 0));
+            if (FS_BOUND(c >= 0 && c < a.n, 7)) a.sums[slot * FS_NACC + q_out] = x;
         }
         if (tid == 0) {
             // tier that must re-score the candidate (0: done) | chunks scanned per pass << 4 (the finish kernel's voxel ratio)
@@ -870,12 +882,16 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             // barrier — for a memory round trip)
             if (!GLOBAL_TABLE && a.costmap) atomicMax(&a.costmap[cur_key & (FS_COST_BINS - 1)], lm_tested);
             if (!GLOBAL_TABLE && n_parts > 1 && !failed) atomicAdd(&a.counters[1], 1ull);   // scored in several passes
-            if (failed && !GLOBAL_TABLE) {
+            // (SPLIT: the first of a pose's items to fail hands the WHOLE pose over, once; the HBM tier's result then replaces the
+            // partial sums — flag 2 tells the finish kernel to read the pose's first slot alone)
+            const bool hand_over = failed && !GLOBAL_TABLE && (!SPLIT || (atomicOr(&a.split_flags[c], 1u) & 1u) == 0u);
+            if (hand_over) {
                 const unsigned long long slot = atomicAdd(&a.counters[2], 1ull);
                 if (FS_BOUND(slot < (unsigned long long)a.n, 4)) a.flagged[slot] = c;          // work list of the HBM tier
-            } else if (failed) {
+            } else if (failed && GLOBAL_TABLE) {
                 atomicAdd(&a.counters[3], 1ull);
             }
+            if (GLOBAL_TABLE && a.split_shift > 0 && !failed) atomicOr(&a.split_flags[c], 2u);
         }
         cur = nxt;
         cur_key = next_key;
@@ -904,14 +920,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 
 // LDS tier: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
 // (two workgroups of 8 waves per CU = 4 waves per SIMD: the register allocator must stay within 128 VGPRs)
-template <int THREADS, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY>
+template <int THREADS, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY, bool SPLIT = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FS_T1_WAVES_PER_EU)))
 void fs_fim_kernel(const FsFimArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
     const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
     constexpr int MASK_SETS = (CONE == FS_CONE_OFF && !INFO_ONLY) ? 2 : 1;      // (= SUMS_AT_TEST of the worker)
-    fim_worker<THREADS, false, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups, MASK_SETS), a.hash_bits);
+    fim_worker<THREADS, false, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY, SPLIT>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups, MASK_SETS), a.hash_bits);
 }
 
 // HBM tier: candidates the LDS tier appended to its work list; table in HBM with 2x the landmark count of slots and
@@ -943,7 +959,7 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
             const unsigned long long scanned = (unsigned long long)(ov >> 4) * 64ull;
             // (only candidates big enough to come near the decision count: a pose at the cloud's edge with one chunk of 64 landmarks
             // in 64 voxels says nothing about the crowded ones)
-            if ((ov & 15u) == 0u && scanned >= 16384ull) {
+            if ((ov & 15u) == 0u && scanned >= 16384ull && a.split_shift == 0) {
                 const uint32_t nv = (uint32_t)(a.sums[(size_t)c * FS_NACC + 17] + 0.5);
                 r = (uint32_t)(((unsigned long long)nv * 256ull + scanned - 1ull) / scanned);
             }
@@ -960,9 +976,17 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
     }
     if (c >= a.n) return;
     if (a.info_only) {                                       // isPoseSafe's scalar and the voxel count: nothing else was accumulated
-        const double *S1 = a.sums + (size_t)c * FS_NACC;
-        a.info_ref[c] = (float)S1[0];
-        a.n_voxels[c] = (int)(S1[17] + 0.5);
+        const double *S1 = a.sums + ((size_t)c << a.split_shift) * FS_NACC;
+        double info = S1[0], nvox = S1[17];
+        if (a.split_shift > 0) {
+            // one pose over W workgroups: the W partial sums — unless the HBM tier redid the whole pose (flag 2: first slot alone)
+            const uint32_t flags = a.split_flags[c];
+            a.split_flags[c] = 0u;                           // (left clean for the next call)
+            if (!(flags & 2u))
+                for (int w = 1; w < (1 << a.split_shift); ++w) { info += S1[(size_t)w * FS_NACC]; nvox += S1[(size_t)w * FS_NACC + 17]; }
+        }
+        a.info_ref[c] = (float)info;
+        a.n_voxels[c] = (int)(nvox + 0.5);
         return;
     }
     const double *S = a.sums + (size_t)c * FS_NACC;
@@ -1075,11 +1099,11 @@ hipError_t allow_lds(K kernel, size_t bytes)
 
 namespace {
 
-template <bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY>
+template <bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY, bool SPLIT = false>
 hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
 {
     const size_t lds = lds_bytes<FS_T1_THREADS>(a.hash_bits, false, a.n_chunks, &a.n_groups, (CONE == FS_CONE_OFF && !INFO_ONLY) ? 2 : 1);
-    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY>;
+    auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY, SPLIT>;
     hipError_t e = allow_lds(kernel, lds);
     if (e != hipSuccess) return e;
     static int resident = 0;                                   // same kernel, same LDS budget class: query once (per instantiation)
@@ -1103,6 +1127,13 @@ hipError_t launch_overflow(FsFimArgs &a, int pool, hipStream_t s)
 
 }  // namespace
 
+// one pose over several workgroups (FsFimArgs::split_shift) exists for the INFO_ONLY LDS worker only
+bool fs_fim_can_split(const FsFimArgs &a)
+{
+    const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
+    return a.table_full && cone != FS_CONE_ANY && a.info_only;
+}
+
 // which learnt voxel ratio a call works with (FsFimArgs::ratio_slot): 13 where the LDS worker that runs hashes from the chunks that
 // can meet the table's box (cone off: SUMS_AT_TEST; INFO_ONLY), 12 where it hashes from everything in range and cone
 static int ratio_slot_of(const FsFimArgs &a)
@@ -1118,6 +1149,7 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
     FsFimArgs a = a0;
     a.ratio_slot = ratio_slot_of(a);
     const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
+    if (a.split_shift > 0 && !fs_fim_can_split(a)) return hipErrorInvalidValue;   // (the host asks fs_fim_can_split before it sets the shift)
     // The specialised workers exist for finite tables (every generated one) and the two common cone modes; anything else runs the
     // general worker, which computes a superset (the finish kernel then hands out what was asked for).
     // (the cone-off workers size their passes by the chunks that can meet the table's box — SUMS_AT_TEST, INFO_ONLY —, and a pose
@@ -1131,6 +1163,8 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
     }
     // (info_only comes from fs_score_fim, whose poses are general; the fused path — the one with yaw-only poses — always wants
     // the full records: the two flags never meet, and no INFO_ONLY x YAW_ONLY worker is instantiated)
+    if (a.info_only && a.split_shift > 0)
+        return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false, true>(a, s);
     if (a.info_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false>(a, s);
     return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, true>(a, s);
 }

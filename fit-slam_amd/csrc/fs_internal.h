@@ -169,6 +169,11 @@ struct FsFimArgs {
     // workers hash from).  Two bases, two ratios: a pose shows up to twice as many voxels per landmark of the second kind.
     // Set by the launchers (fs_fim.hip), not by the caller.
     int32_t ratio_slot;
+    // One pose over W = 2^split_shift workgroups (INFO_ONLY LDS worker; fs_fim.hip, SPLIT): cand_count = n * W work items, sums
+    // [n * W][18], split_flags [n] (zero between calls: bit 0 a pose's item has handed the pose to the HBM tier, bit 1 the HBM
+    // tier's result stands in the pose's first slot).  0: off.
+    int32_t split_shift;
+    uint32_t *split_flags;
     float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;
@@ -232,6 +237,7 @@ hipError_t fs_launch_sort_candidates(int32_t n, const double *d_goal, const FsGr
                                     void **scratch, size_t *scratch_bytes, unsigned long long *d_cost_acc,
                                     const uint32_t **d_keys, uint32_t **d_costmap, int use_costmap, int reverse, hipStream_t s);
 hipError_t fs_launch_fim(const FsFimArgs &a, hipStream_t s);
+bool fs_fim_can_split(const FsFimArgs &a);     // may split_shift be set for this call? (needs info_only, cone_mode, table_full filled in)
 hipError_t fs_launch_fim_overflow(const FsFimArgs &a, int pool, hipStream_t s);
 hipError_t fs_launch_fim_finish(const FsFimArgs &a, hipStream_t s);
 hipError_t fs_launch_selftest(int32_t max_abs, double *d_sqrt, double *d_div, hipStream_t s);

@@ -190,6 +190,69 @@ def test_fim_learnt_pass_prediction_is_only_a_prediction(fs, oracle, scorer, ref
     assert scorer.get_counter(5) > hbm0
 
 
+@pytest.mark.parametrize("angle", [1.0, 4.0])
+def test_one_pose_over_several_workgroups(fs, oracle, scorer, ref_table, angle):
+    """A call with few poses asks for info_ref alone (isPoseSafe: one pose per tick, FisherInfoBTPlugin.cpp:24-57) and spreads each
+    pose over W = 2, 4, 8, 16 workgroups by voxel slab ("fim.split" = log2 W; fs_fim.hip SPLIT).  Whole voxels stay in one
+    workgroup, so n_voxels is exact and the information is the same multiset of terms: equal to the unsplit call and the oracle
+    for 1 .. 100 poses (beyond 256 / W poses the call falls back to fewer workgroups per pose, then to none)."""
+    w = fs.synth.make_workload("REF2D", n_cand=100)
+    rng = np.random.default_rng(5)
+    poses = fs.synth.poses_from_yaw(w.goals, rng.uniform(-np.pi, np.pi, 100))
+    poses[:, 2] = 0.4
+    q = rng.normal(size=(6, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses[:6, 3:] = q
+    scorer.upload_landmarks(w.landmarks)
+    scorer.lookup_generate()
+    scorer.set_fim_params(14.0, angle)
+    want = oracle.pose_information(ref_table, w.landmarks, poses, 14.0, angle, n_threads=8)
+    scale = np.maximum(np.abs(want["info_f64"]), 1e-6)
+    try:
+        for split in (0, 1, 2, 3, 4):
+            scorer.set_option("fim.split", split)
+            for n in (1, 2, 5, 31, 100):
+                for _ in range(2):                                   # twice: the flags of a split call are left clean for the next
+                    got = scorer.score_fim(poses[:n], info_only=True)
+                    np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"][:n], err_msg=f"split {split} n {n}")
+                    assert np.max(np.abs(got["info_ref"] - want["info_f64"][:n]) / scale[:n]) <= REL, (split, n)
+    finally:
+        scorer.set_option("fim.split", 3)
+
+
+def test_split_pose_that_overflows_goes_to_the_hbm_tier_whole(fs, oracle, scorer, ref_table):
+    """The split workers size their tables by the learnt voxel ratio, like the unsplit ones.  Train the ratio on poses inside a
+    dense clump, then ask for poses in a sparse region where nearly every landmark has a voxel of its own: the items of such a pose
+    overflow, the FIRST to fail hands the whole pose to the HBM tier (once), and the finish kernel takes that result instead of
+    the partial sums."""
+    rng = np.random.default_rng(23)
+    dense = (np.array([4.0, 0.0, 0.0]) + rng.uniform(-1.5, 1.5, size=(60000, 3))).astype(np.float32)
+    sparse = rng.normal(size=(60000, 3))
+    sparse = sparse / np.linalg.norm(sparse, axis=1, keepdims=True) * (13.5 * rng.random(60000) ** (1 / 3))[:, None]
+    sparse[:, 0] = np.abs(sparse[:, 0]) + 200.0
+    lm = np.concatenate([dense, sparse.astype(np.float32)])
+    near = np.zeros((8, 7)); near[:, 6] = 1.0; near[:, 1] = np.linspace(-0.3, 0.3, 8)
+    far = np.zeros((2, 7)); far[:, 6] = 1.0; far[:, 0] = 200.0; far[1, 2] = 0.2
+    scorer.upload_landmarks(lm)
+    scorer.set_fim_params(14.0, 1.5)
+    scorer.set_option("fim.split", 0)
+    try:
+        for _ in range(2):
+            scorer.score_fim(np.repeat(near, 40, axis=0), info_only=True)        # 320 poses: unsplit, and big enough to teach the ratio
+        scorer.set_option("fim.split", 3)
+        mixed = np.concatenate([near[:3], far])
+        want = oracle.pose_information(ref_table, lm, mixed, 14.0, 1.5, n_threads=8)
+        assert want["n_voxels"][3:].min() > 16384
+        hbm0 = scorer.get_counter(5)
+        for _ in range(2):
+            got = scorer.score_fim(mixed, info_only=True)
+            np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
+            sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
+            assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= REL
+        assert scorer.get_counter(5) > hbm0                           # the HBM tier did take poses
+    finally:
+        scorer.set_option("fim.split", 3)
+
+
 def test_fim_voxel_rounding_next_to_the_boundary(fs, oracle, scorer, ref_table):
     """getVoxelCoordinate rounds x / step in double; the kernel rounds an fp32 product and re-evaluates in fp64 only inside a band
     around the half-integers whose width follows the visibility range (FsFimArgs::key_thr).  Landmarks ON the boundaries and a
