@@ -918,34 +918,10 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
 #endif
 }
 
-// LDS tier: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
-// (two workgroups of 8 waves per CU = 4 waves per SIMD: the register allocator must stay within 128 VGPRs)
-template <int THREADS, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY, bool SPLIT = false>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FS_T1_WAVES_PER_EU)))
-void fs_fim_kernel(const FsFimArgs a)
+// One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.  Called by every lane of whole
+// waves (the per-wave reductions below shuffle over all 64 lanes; c >= a.n lanes only take part in those).
+__device__ __forceinline__ void finish_body(const FsFimArgs &a, const int c)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
-    constexpr int MASK_SETS = (CONE == FS_CONE_OFF && !INFO_ONLY) ? 2 : 1;      // (= SUMS_AT_TEST of the worker)
-    fim_worker<THREADS, false, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY, SPLIT>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups, MASK_SETS), a.hash_bits);
-}
-
-// HBM tier: candidates the LDS tier appended to its work list; table in HBM with 2x the landmark count of slots and
-// unbounded probing
-template <int THREADS, bool TABLE_FULL>
-__global__ __launch_bounds__(THREADS)
-void fs_fim_tier3_kernel(const FsFimArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
-    const FimWork work{a.flagged, 0, (int)a.counters[2], a.counters + 9};
-    uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
-    fim_worker<THREADS, true, TABLE_FULL, FS_CONE_ANY, false, false>(a, work, fs_fim_lds, table, a.ghash_bits);
-}
-
-// One thread per candidate: assemble the 6x6 FIM from the 15 block sums, trace, log det.
-__global__ void fs_fim_finish_kernel(const FsFimArgs a)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     {   // landmark-test count of this block's candidates -> one atomic per block
         unsigned long long tsum = (c < a.n) ? (unsigned long long)a.tested[c] : 0ull;
         if (c < a.n) a.tested[c] = 0u;
@@ -1065,6 +1041,49 @@ __global__ void fs_fim_finish_kernel(const FsFimArgs a)
         r.flags = (a.rec_achievable[c] ? FS_FLAG_ACHIEVABLE : 0u) | (((uint32_t)a.status[c] & 0xffu) << 8) |
                   ((nv > 65535u ? 65535u : nv) << 16);
         a.records[c] = r;
+    }
+}
+
+__global__ void fs_fim_finish_kernel(const FsFimArgs a)
+{
+    finish_body(a, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+
+// LDS tier: persistent workgroups (two per CU) pull candidates of the processing order from a device-side counter
+// (two workgroups of 8 waves per CU = 4 waves per SIMD: the register allocator must stay within 128 VGPRs)
+template <int THREADS, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY, bool SPLIT = false>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(FS_T1_WAVES_PER_EU)))
+void fs_fim_kernel(const FsFimArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
+    const FimWork work{a.cand_perm, a.cand_lo, a.cand_count, a.counters + 8};
+    constexpr int MASK_SETS = (CONE == FS_CONE_OFF && !INFO_ONLY) ? 2 : 1;      // (= SUMS_AT_TEST of the worker)
+    fim_worker<THREADS, false, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY, SPLIT>(a, work, fs_fim_lds, Lds<THREADS>::table(fs_fim_lds, a.n_groups, MASK_SETS), a.hash_bits);
+}
+
+// HBM tier: candidates the LDS tier appended to its work list; table in HBM with 2x the landmark count of slots and
+// unbounded probing
+template <int THREADS, bool TABLE_FULL>
+__global__ __launch_bounds__(THREADS)
+void fs_fim_tier3_kernel(const FsFimArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t fs_fim_lds[];
+    const FimWork work{a.flagged, 0, (int)a.counters[2], a.counters + 9};
+    uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
+    fim_worker<THREADS, true, TABLE_FULL, FS_CONE_ANY, false, false>(a, work, fs_fim_lds, table, a.ghash_bits);
+    // A small call (FsFimArgs::fold_finish) has no finish launch of its own: the workgroup that leaves this kernel LAST does the
+    // finish kernel's work for all n candidates — one launch (4.6 us of GPU timeline even when empty) less per one-pose call.
+    if (a.fold_finish) {
+        __shared__ int sh_last;
+        __threadfence();                                       // this workgroup's sums and flags, before it signs off
+        __syncthreads();
+        if (threadIdx.x == 0) sh_last = atomicAdd(&a.counters[14], 1ull) + 1ull == (unsigned long long)gridDim.x ? 1 : 0;
+        __syncthreads();
+        if (sh_last) {                                         // (uniform over the workgroup)
+            __threadfence();
+            for (int base = 0; base < a.n; base += THREADS) finish_body(a, base + (int)threadIdx.x);
+            if (threadIdx.x == 0) a.counters[14] = 0ull;
+        }
     }
 }
 

@@ -220,14 +220,15 @@ def test_one_pose_over_several_workgroups(fs, oracle, scorer, ref_table, angle):
 
 
 def test_split_pose_that_overflows_goes_to_the_hbm_tier_whole(fs, oracle, scorer, ref_table):
-    """The split workers size their tables by the learnt voxel ratio, like the unsplit ones.  Train the ratio on poses inside a
-    dense clump, then ask for poses in a sparse region where nearly every landmark has a voxel of its own: the items of such a pose
-    overflow, the FIRST to fail hands the whole pose to the HBM tier (once), and the finish kernel takes that result instead of
-    the partial sums."""
+    """A split workgroup sizes its table for its share of the landmarks scanned, so it overflows only where even that share holds
+    more distinct voxels than the largest LDS table has slots.  Poses in a sparse half ball of 200 k landmarks show > 2 x 16 384
+    voxels each; spread over W = 2 workgroups on a ratio learnt from a dense clump (one pass predicted), both items of such a pose
+    run out of table: the FIRST to fail hands the whole pose to the HBM tier — once —, and the finish takes that result instead
+    of the partial sums.  The poses next to the clump stay split and in LDS."""
     rng = np.random.default_rng(23)
     dense = (np.array([4.0, 0.0, 0.0]) + rng.uniform(-1.5, 1.5, size=(60000, 3))).astype(np.float32)
-    sparse = rng.normal(size=(60000, 3))
-    sparse = sparse / np.linalg.norm(sparse, axis=1, keepdims=True) * (13.5 * rng.random(60000) ** (1 / 3))[:, None]
+    sparse = rng.normal(size=(200000, 3))
+    sparse = sparse / np.linalg.norm(sparse, axis=1, keepdims=True) * (13.5 * rng.random(200000) ** (1 / 3))[:, None]
     sparse[:, 0] = np.abs(sparse[:, 0]) + 200.0
     lm = np.concatenate([dense, sparse.astype(np.float32)])
     near = np.zeros((8, 7)); near[:, 6] = 1.0; near[:, 1] = np.linspace(-0.3, 0.3, 8)
@@ -238,17 +239,20 @@ def test_split_pose_that_overflows_goes_to_the_hbm_tier_whole(fs, oracle, scorer
     try:
         for _ in range(2):
             scorer.score_fim(np.repeat(near, 40, axis=0), info_only=True)        # 320 poses: unsplit, and big enough to teach the ratio
-        scorer.set_option("fim.split", 3)
         mixed = np.concatenate([near[:3], far])
         want = oracle.pose_information(ref_table, lm, mixed, 14.0, 1.5, n_threads=8)
-        assert want["n_voxels"][3:].min() > 16384
-        hbm0 = scorer.get_counter(5)
-        for _ in range(2):
-            got = scorer.score_fim(mixed, info_only=True)
-            np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
-            sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
-            assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= REL
-        assert scorer.get_counter(5) > hbm0                           # the HBM tier did take poses
+        assert want["n_voxels"][3:].min() > 2 * 16384
+        sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
+        for split in (1, 3):
+            scorer.set_option("fim.split", split)
+            hbm0 = scorer.get_counter(5)
+            for _ in range(2):
+                got = scorer.score_fim(mixed, info_only=True)
+                np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
+                assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= REL
+            if split == 1:
+                assert scorer.get_counter(5) >= hbm0 + 2                  # the HBM tier took the far poses (each ONCE per call)
+                assert scorer.get_counter(5) <= hbm0 + 4
     finally:
         scorer.set_option("fim.split", 3)
 
