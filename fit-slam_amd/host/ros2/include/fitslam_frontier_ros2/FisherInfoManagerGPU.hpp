@@ -33,7 +33,10 @@ class FisherInformationManagerGPU
 {
 public:
     // FisherInfoManager.cpp:6-16: loads the lookup table at construction (throws when the file is missing, :240)
-    explicit FisherInformationManagerGPU(std::shared_ptr<nav2_util::LifecycleNode> node, int device_id = 0,
+    // device_ids: HIP ordinals to score on; empty = the node's parameter `fitslam_frontier.gpu_devices` (default [0]) — the same
+    // list CostAssignerGPU reads: one isPoseSafe pose runs on the first device, a batch (poseInformation) is cut into one
+    // contiguous block per device (fs_multi_score_fim)
+    explicit FisherInformationManagerGPU(std::shared_ptr<nav2_util::LifecycleNode> node, std::vector<int> device_ids = {},
                                          const std::string &lookup_file = "/root/dev_ws/src/lookup_table_fi/fisher_information_lookup_table.dat");
     ~FisherInformationManagerGPU();
     FisherInformationManagerGPU(const FisherInformationManagerGPU &) = delete;
@@ -58,7 +61,7 @@ private:
     void mapDataCallback(const slam_msgs::msg::MapData::SharedPtr map_data);
     void check(int rc, const char *what) const;
 
-    fs_ctx *ctx_ = nullptr;
+    fs_multi *scorer_ = nullptr;                 // one fs_ctx per GPU of the device list, one calling thread at a time (ctx_mutex_)
     std::string lookup_file_;
     std::shared_ptr<nav2_util::LifecycleNode> node_;
     rclcpp::Node::SharedPtr client_node_;

@@ -14,12 +14,18 @@
 namespace fitslam_frontier_ros2
 {
 
-FisherInformationManagerGPU::FisherInformationManagerGPU(std::shared_ptr<nav2_util::LifecycleNode> node, int device_id,
+FisherInformationManagerGPU::FisherInformationManagerGPU(std::shared_ptr<nav2_util::LifecycleNode> node, std::vector<int> device_ids,
                                                          const std::string &lookup_file)
     : lookup_file_(lookup_file), node_(node)
 {
-    if (fs_ctx_create(device_id, nullptr, &ctx_) != FS_OK)
-        throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) device or HIP runtime; there is no CPU fallback");
+    if (device_ids.empty()) {                                                    // the list CostAssignerGPU reads, too
+        std::vector<int64_t> ids{0};
+        if (!node_->has_parameter("fitslam_frontier.gpu_devices")) node_->declare_parameter("fitslam_frontier.gpu_devices", ids);
+        node_->get_parameter("fitslam_frontier.gpu_devices", ids);
+        for (const int64_t d : ids) device_ids.push_back(static_cast<int>(d));
+    }
+    if (fs_multi_create(device_ids.data(), static_cast<int>(device_ids.size()), &scorer_) != FS_OK)
+        throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) under one of fitslam_frontier.gpu_devices; there is no CPU fallback");
     // Which landmarks a pose "sees" is the reference's REQUEST to the SLAM server (FisherInfoManager.cpp:63-64):
     // max_dist_pose_observation = 14.0, max_angle_pose_observation = 4.0 — "greater than pi to disregard angle of
     // observation".  Those two numbers are this manager's defaults, as node parameters of the same names, so that
@@ -34,7 +40,7 @@ FisherInformationManagerGPU::FisherInformationManagerGPU(std::shared_ptr<nav2_ut
     fs_fim_params vis;
     vis.max_dist = max_dist;
     vis.max_angle = max_angle;
-    check(fs_set_fim_params(ctx_, &vis), "fs_set_fim_params");
+    check(fs_multi_set_fim_params(scorer_, &vis), "fs_multi_set_fim_params");
     loadLookupTable();                                                           // :10
 
     client_node_ = rclcpp::Node::make_shared("FIMManagerGPUClient");             // :9 (same pattern: a node of its own)
@@ -53,26 +59,28 @@ FisherInformationManagerGPU::~FisherInformationManagerGPU()
     if (spin_thread_.joinable()) spin_thread_.join();
     map_data_subscription_.reset();
     client_node_.reset();
-    fs_ctx_destroy(ctx_);
+    fs_multi_destroy(scorer_);
 }
 
 void FisherInformationManagerGPU::check(int rc, const char *what) const
 {
-    if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_last_error(ctx_));
+    if (rc != FS_OK) throw std::runtime_error(std::string(what) + ": " + fs_multi_last_error(scorer_));
 }
 
 void FisherInformationManagerGPU::generateLookupTable(float minX, float maxX, float minY, float maxY, float minZ, float maxZ)
 {
     std::lock_guard<std::mutex> lock(ctx_mutex_);
     const float bounds[6] = {minX, maxX, minY, maxY, minZ, maxZ};
-    check(fs_lookup_generate(ctx_, bounds), "fs_lookup_generate");               // FisherInfoManager.cpp:117-229
-    check(fs_lookup_save(ctx_, lookup_file_.c_str()), "fs_lookup_save");         // byte-compatible 16-B records
+    check(fs_multi_lookup_generate(scorer_, bounds), "fs_multi_lookup_generate");   // FisherInfoManager.cpp:117-229 (generated once, handed to every device)
+    fs_ctx *first = fs_multi_ctx(scorer_, 0);
+    if (fs_lookup_save(first, lookup_file_.c_str()) != FS_OK)                    // byte-compatible 16-B records
+        throw std::runtime_error(std::string("fs_lookup_save: ") + fs_last_error(first));
 }
 
 void FisherInformationManagerGPU::loadLookupTable()
 {
     std::lock_guard<std::mutex> lock(ctx_mutex_);
-    if (fs_lookup_load(ctx_, lookup_file_.c_str()) != FS_OK)                     // :231-262
+    if (fs_multi_lookup_load(scorer_, lookup_file_.c_str()) != FS_OK)            // :231-262
         throw std::runtime_error("Cannot load lookup table. Does it exist in the path?");
 }
 
@@ -82,13 +90,13 @@ void FisherInformationManagerGPU::setVisibility(double max_dist, double max_angl
     fs_fim_params vis;
     vis.max_dist = max_dist;
     vis.max_angle = max_angle;
-    check(fs_set_fim_params(ctx_, &vis), "fs_set_fim_params");
+    check(fs_multi_set_fim_params(scorer_, &vis), "fs_multi_set_fim_params");
 }
 
 void FisherInformationManagerGPU::setLandmarks(const std::vector<float> &xyz_world)
 {
     std::lock_guard<std::mutex> lock(ctx_mutex_);
-    check(fs_upload_landmarks(ctx_, xyz_world.data(), static_cast<int32_t>(xyz_world.size() / 3)), "fs_upload_landmarks");
+    check(fs_multi_upload_landmarks(scorer_, xyz_world.data(), static_cast<int32_t>(xyz_world.size() / 3)), "fs_multi_upload_landmarks");
     have_landmarks_ = true;
 }
 
@@ -138,8 +146,10 @@ bool FisherInformationManagerGPU::poseInformation(const std::vector<geometry_msg
         o[3] = p.orientation.x; o[4] = p.orientation.y; o[5] = p.orientation.z; o[6] = p.orientation.w;
     }
     std::lock_guard<std::mutex> lock(ctx_mutex_);
-    return fs_score_fim(ctx_, static_cast<int32_t>(poses.size()), pose7.data(), information.data(),
-                        nullptr, nullptr, nullptr, nullptr, nullptr) == FS_OK;
+    // info_ref alone (NULL for every other column): the INFO_ONLY worker — and, for the few poses of a tick, each pose spread over
+    // several workgroups of its device (include/fitslam_frontier_dev.h, "fim.split")
+    return fs_multi_score_fim(scorer_, static_cast<int32_t>(poses.size()), pose7.data(), information.data(),
+                              nullptr, nullptr, nullptr, nullptr, nullptr) == FS_OK;
 }
 
 bool FisherInformationManagerGPU::isPoseSafe(geometry_msgs::msg::Pose &given_pose, bool exhaustiveSearch, float &information)

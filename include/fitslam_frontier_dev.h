@@ -31,7 +31,9 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * knob for measuring how much the order matters.
  * "ray.layout" (default 0): which image of the grid the arrival fan walks — 0 picks by ray length (row-major byte image below
  * 96 cells on 2-D maps, the 2-bit class image in 8 x 8 x 8-cell bricks on 3-D grids and from there on: the measured winners), 1 / 2 force the byte / class
- * walk (identical results in every case; DESIGN.md 4.1 holds the measured table).
+ * walk (identical results in every case; DESIGN.md 4.1 holds the measured table); 3 = the class image as a brick table + a pool
+ * of distinct bricks (BASELINE.json configs[4]'s "sparse" form: 2.6x smaller, half the L2 traffic, 40 % SLOWER — an experiment kept
+ * reproducible, profiles/EXPERIMENTS.md).
  * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
  * landmarks scanned, in 32nds, that decides the number of scoring passes — the cap under which the worker uses what
  * finished calls on the cloud have shown: DESIGN.md 4.2).
@@ -46,13 +48,21 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * up to 4 poses) replay a captured launch graph instead of launching their kernels one by one (identical results).  Measured
  * 5-7 us slower per call than plain launches on ROCm 7.2 (profiles/r04/small_call_graphs.json), hence off; never used while
  * kernel timing is enabled.
+ * "fim.split" (default 3): fs_score_fim asked for info_ref alone with so few poses that the chip would idle spreads each pose
+ * over up to 2^value workgroups by voxel slab (all n * W items resident, >= 128 landmark chunks per workgroup); 0 = one
+ * workgroup per pose.  Identical n_voxels, the same multiset of information terms.  (One isPoseSafe pose at the reference's
+ * visibility request: 60 -> 46 us.)
+ * "fim.fold" (default 1): calls of up to 2048 poses / candidates run the finish step inside the HBM-tier launch (its last
+ * workgroup) instead of a launch of its own; 0 = three launches.  Identical results; not used while kernel timing is enabled.
  * "fim.specialise" (default 1): 0 = always the general FIM worker (no INFO_ONLY / YAW_ONLY instantiation; identical integers,
  * float sums to the last bits) — the A/B switch of tests/test_gpu_reference_visibility.py. */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
 /* Device-side counters: 0 = landmark visibility tests performed (M_tested summed over candidates),
  * 4 = candidates scored in several voxel-partitioned passes, 5 = candidates re-scored with the table in HBM,
- * 6 = unresolved (always 0), 12 = the largest voxels-per-landmark ratio (in 1/256) a big candidate of the finished calls
- * showed (the pass prediction's input; reset with the cloud, the table and the visibility volume). */
+ * 6 = unresolved (always 0), 12 / 13 = the largest voxels-per-landmark ratio (in 1/256) a big candidate of the finished calls
+ * showed (the pass prediction's input; reset with the cloud, the table and the visibility volume) — 12 per landmark of the
+ * chunks in range and cone (the cone workers), 13 per landmark of the chunks that can also meet the lookup table's box (the
+ * cone-off and info-only workers).  Host-side: 1000 / 1001 = bricks of the grid / bricks in the pool of "ray.layout" 3. */
 int  fs_get_counter(fs_ctx *ctx, int which, int64_t *value, int reset);
 
 /* ---------------------------------------------------------------- self test */

@@ -73,9 +73,9 @@ def test_a_wrong_abi_call_is_caught(tmp_path):
         p.parent.mkdir(parents=True, exist_ok=True)
         p.write_text(f'#include "{DECLS}"\n')
     src = open(os.path.join(PKG, "src", "FisherInfoManagerGPU.cpp")).read()
-    assert "fs_upload_landmarks(ctx_, xyz_world.data()," in src
+    assert "fs_multi_upload_landmarks(scorer_, xyz_world.data()," in src
     bad = tmp_path / "bad.cpp"
-    bad.write_text(src.replace("fs_upload_landmarks(ctx_, xyz_world.data(),", "fs_upload_landmarks(xyz_world.data(), ctx_,"))
+    bad.write_text(src.replace("fs_multi_upload_landmarks(scorer_, xyz_world.data(),", "fs_multi_upload_landmarks(xyz_world.data(), scorer_,"))
     res = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-I", str(shim), "-I", os.path.join(PKG, "include"),
                           "-I", os.path.join(ROOT, "include"), str(bad)], capture_output=True, text=True)
     assert res.returncode != 0

@@ -67,7 +67,9 @@ def test_adapter_calls_only_declared_abi_entry_points():
     assert used and used <= declared, used - declared
     # the batched calls that replace the reference's per-frontier loop and per-pose service call
     assert {"fs_multi_create", "fs_multi_score_arrival", "fs_rank_candidates", "fs_multi_max_arrival", "fs_multi_upload_grid",
-            "fs_score_fim", "fs_upload_landmarks", "fs_lookup_load"} <= used
+            "fs_multi_get_frontier_costs", "fs_multi_score_fim", "fs_multi_upload_landmarks", "fs_multi_lookup_load"} <= used
+    # one in-process multi-device object per class, no second single-device context next to it
+    assert "fs_ctx_create" not in used
 
 
 def test_cost_assigner_keeps_the_reference_interface():
@@ -94,6 +96,8 @@ def test_adapter_follows_the_reference_request_and_loads_next_to_the_reference_p
     assert plug.index("if (!have_evaluate && !have_mark)") < plug.index('factory.unregisterBuilder("EvaluateFisherInformation")')
     ca = _read("src", "CostAssignerGPU.cpp")
     assert '"fitslam_frontier.gpu_devices"' in ca and "fs_multi_create" in ca and "fs_ctx_create" not in ca
+    assert '"fitslam_frontier.gpu_devices"' in fim and "fs_multi_create" in fim and "fs_ctx_create" not in fim
+    assert "setFused" in _read("include", "fitslam_frontier_ros2", "CostAssignerGPU.hpp") and "assignCostsFused" in ca
     # the two bodies the copy check flagged in round 2 are no longer the reference's statements
     for ref_name in ("min_x_polygon", "max_y_polygon", "frontiers_list", "geometry_msgs::msg::Point32 temp"):
         assert ref_name not in ca, ref_name
