@@ -187,7 +187,6 @@ struct fs_ctx {
     DevBuf<uint8_t> d_black, d_achin, d_ach;
     DevBuf<float> d_info, d_trace, d_logdet, d_fim21, d_Rt;
     DevBuf<uint32_t> d_overflow, d_tested, d_split_flags;
-    bool opt_fold = true;          // "fim.fold": small calls run the finish inside the HBM-tier launch
     int opt_split = 3;             // "fim.split": log2 of the workgroups ONE info-only pose is spread over when a call has few poses (0: off)
     DevBuf<int32_t> d_flagged;
     size_t tested_zeroed = 0;
@@ -1447,7 +1446,6 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "fim.fold") == 0) { c->opt_fold = value != 0; ++c->epoch; return FS_OK; }
     if (std::strcmp(key, "fim.split") == 0 && value >= 0 && value <= 5) { c->opt_split = (int)value; ++c->epoch; return FS_OK; }
     if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 3) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
@@ -1576,18 +1574,16 @@ static int run_fim_tier1(fs_ctx *c, FsFimArgs &a, const int32_t *perm, int32_t l
     return FS_OK;
 }
 
-#define FS_FOLD_FINISH_MAX_N 2048   // poses / candidates up to which the HBM-tier launch's last workgroup also runs the finish
 static int run_fim_rest(fs_ctx *c, FsFimArgs &a)
 {
-    // a small call is launch latency: its finish rides in the HBM-tier launch (one launch less).  Not while kernel
-    // timing is on: kind 2 is the HBM tier's own time.
-    a.fold_finish = (c->opt_fold && !c->timing && a.n <= FS_FOLD_FINISH_MAX_N) ? 1 : 0;
     {
         // the HBM tier exits at once unless the LDS tier flagged a candidate (device-side work list)
         ScopedTimer t(c, 2);
         FS_HIP(c, fs_launch_fim_overflow(a, fs_ctx::kPool, c->stream));
     }
-    if (!a.fold_finish) FS_HIP(c, fs_launch_fim_finish(a, c->stream));
+    // (a launch of its own on purpose: running the finish inside the HBM-tier launch — its last workgroup, found with a sign-off
+    // counter — measured 6-8 us SLOWER per small call than the launch it saves: profiles/EXPERIMENTS.md, round 5)
+    FS_HIP(c, fs_launch_fim_finish(a, c->stream));
     return FS_OK;
 }
 

@@ -1071,20 +1071,6 @@ void fs_fim_tier3_kernel(const FsFimArgs a)
     const FimWork work{a.flagged, 0, (int)a.counters[2], a.counters + 9};
     uint32_t *table = a.gtable + ((size_t)blockIdx.x << a.ghash_bits);
     fim_worker<THREADS, true, TABLE_FULL, FS_CONE_ANY, false, false>(a, work, fs_fim_lds, table, a.ghash_bits);
-    // A small call (FsFimArgs::fold_finish) has no finish launch of its own: the workgroup that leaves this kernel LAST does the
-    // finish kernel's work for all n candidates — one launch (4.6 us of GPU timeline even when empty) less per one-pose call.
-    if (a.fold_finish) {
-        __shared__ int sh_last;
-        __threadfence();                                       // this workgroup's sums and flags, before it signs off
-        __syncthreads();
-        if (threadIdx.x == 0) sh_last = atomicAdd(&a.counters[14], 1ull) + 1ull == (unsigned long long)gridDim.x ? 1 : 0;
-        __syncthreads();
-        if (sh_last) {                                         // (uniform over the workgroup)
-            __threadfence();
-            for (int base = 0; base < a.n; base += THREADS) finish_body(a, base + (int)threadIdx.x);
-            if (threadIdx.x == 0) a.counters[14] = 0ull;
-        }
-    }
 }
 
 template <int THREADS>

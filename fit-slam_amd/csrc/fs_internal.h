@@ -174,7 +174,6 @@ struct FsFimArgs {
     // tier's result stands in the pose's first slot).  0: off.
     int32_t split_shift;
     uint32_t *split_flags;
-    int32_t fold_finish;       // 1: the HBM-tier launch also does the finish kernel's work (its last workgroup; counters[14] counts them) — small calls
     float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;
@@ -201,7 +200,7 @@ struct FsFimArgs {
     const double *rec_yaw;
     const uint8_t *rec_achievable;
     unsigned long long *counters;   // [16]: 0 landmarks tested; per call 1 multi-pass candidates, 2 handed to the HBM tier, 3 unresolved; 4..6 their running totals; 8 / 9 work-list cursors of the LDS / HBM tier;
-                                    // 10 / 11 landmark tests / candidates since the last spatial sort (its cost-map mean); 12 / 13 learnt voxel ratios (ratio_slot); 14 workgroups of the HBM-tier launch that have signed off (fold_finish)
+                                    // 10 / 11 landmark tests / candidates since the last spatial sort (its cost-map mean); 12 / 13 learnt voxel ratios (ratio_slot)
     // hash tables
     int32_t hash_bits;         // LDS tier (512-thread workgroups)
     int32_t skip32;            // pass-count prediction: distinct voxels <= skip32/32 of the landmarks scanned

@@ -52,8 +52,6 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * over up to 2^value workgroups by voxel slab (all n * W items resident, >= 128 landmark chunks per workgroup); 0 = one
  * workgroup per pose.  Identical n_voxels, the same multiset of information terms.  (One isPoseSafe pose at the reference's
  * visibility request: 60 -> 46 us.)
- * "fim.fold" (default 1): calls of up to 2048 poses / candidates run the finish step inside the HBM-tier launch (its last
- * workgroup) instead of a launch of its own; 0 = three launches.  Identical results; not used while kernel timing is enabled.
  * "fim.specialise" (default 1): 0 = always the general FIM worker (no INFO_ONLY / YAW_ONLY instantiation; identical integers,
  * float sums to the last bits) — the A/B switch of tests/test_gpu_reference_visibility.py. */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
