@@ -847,6 +847,60 @@ public:
         return rec;
     }
 
+    // FrontierCostsManager::assignCosts' device half as ONE call over every device (fs_multi_get_frontier_costs): arrival information
+    // on each block's device, the records gathered device to device onto the first GPU, U1 costs there, one transfer back.  The
+    // planner has run first (FrontierCostsManager::assignCostsFused explains why that gives the reference's results): path_length /
+    // path_heading as it set them, achievable_in = what it left achievable.  Sets the reference's fields on every frontier.
+    void assignCosts(std::vector<FrontierPtr> &frontiers, const std::vector<uint8_t> &blacklisted, const std::vector<uint8_t> &achievable_in,
+                     const std::vector<double> &path_length, const std::vector<double> &path_heading, double delta_theta, double camera_fov,
+                     double alpha = 0.25, double beta = 1.0, double vx_max = 0.5, double wz_max = 0.5)
+    {
+        const int32_t n = (int32_t)frontiers.size();
+        if (n == 0) return;
+        const double dmax = std::numeric_limits<double>::max();
+        std::vector<double> goal(3 * (size_t)n), cost((size_t)n), au((size_t)n), du((size_t)n);
+        std::vector<int32_t> fsize((size_t)n);
+        for (int32_t i = 0; i < n; ++i) {
+            const Point &g = frontiers[i]->getGoalPoint();
+            goal[3 * i] = g.x; goal[3 * i + 1] = g.y; goal[3 * i + 2] = g.z;
+            fsize[i] = frontiers[i]->getSize();
+        }
+        std::vector<fs_record> rec((size_t)n);
+        const int rc = fs_multi_get_frontier_costs(m_, n, goal.data(), fsize.data(), blacklisted.empty() ? nullptr : blacklisted.data(),
+                                                   achievable_in.empty() ? nullptr : achievable_in.data(), path_length.data(), path_heading.data(),
+                                                   alpha, beta, vx_max, wz_max, /*with_fisher_information=*/0, rec.data(), cost.data(), au.data(), du.data(), nullptr);
+        if (rc == FS_E_RANGE) throw std::runtime_error("Cost out of bounds");   // FrontierCostsManager.cpp:148-149,173-174
+        check(rc, "fs_multi_get_frontier_costs");
+        for (int32_t i = 0; i < n; ++i) {
+            auto &f = frontiers[i];
+            if (!blacklisted.empty() && blacklisted[i]) {                         // :77-86
+                f->setArrivalInformation(0.0); f->setGoalOrientation(0.0); f->setFisherInformation(0.0);
+                f->setPathLength(dmax); f->setPathLengthInM(dmax); f->setWeightedCost(dmax);
+            } else {
+                f->setArrivalInformation((double)rec[i].arrival);
+                f->setGoalOrientation(FS_RECORD_STATUS(rec[i].flags) == FS_STATUS_OK ? (double)rec[i].argmax * delta_theta + camera_fov / 2 : 0.0);   // CostCalculator.cpp:119 / :52-54
+                f->setAchievability((rec[i].flags & FS_FLAG_ACHIEVABLE) != 0);
+            }
+            f->setWeightedCost(cost[i]);
+            f->setCost("arrival_gain_utility", au[i]);
+            f->setCost("distance_utility", du[i]);
+        }
+    }
+    // FisherInformationManager::poseInformation over every device (fs_multi_score_fim, info_ref alone)
+    void poseInformation(const std::vector<Pose> &poses, std::vector<float> &information)
+    {
+        std::vector<double> p7(poses.size() * 7);
+        for (size_t i = 0; i < poses.size(); ++i) {
+            const Pose &p = poses[i];
+            const double v[7] = {p.position.x, p.position.y, p.position.z, p.orientation.x, p.orientation.y, p.orientation.z, p.orientation.w};
+            for (int k = 0; k < 7; ++k) p7[7 * i + k] = v[k];
+        }
+        information.assign(poses.size(), 0.0f);
+        check(fs_multi_score_fim(m_, (int32_t)poses.size(), p7.data(), information.data(), nullptr, nullptr, nullptr, nullptr, nullptr), "fs_multi_score_fim");
+    }
+    int gatherMode() const { return fs_multi_gather_mode(m_); }
+    void setOption(const char *key, double value) { check(fs_multi_set_option(m_, key, value), "fs_multi_set_option"); }
+
 private:
     fs_multi *m_ = nullptr;
 };

@@ -229,6 +229,47 @@ int main(int argc, char **argv)
         }
         printf("ShardedScorer({0,0}): %d devices, %d mismatches against the single context\n", sharded.numDevices(), bad);
         if (bad || sharded.numDevices() != 2) ++failures;
+
+        // the whole cost assignment as ONE call over both members (fs_multi_get_frontier_costs: blocks gathered device to device,
+        // ranked on the first): path columns as the planner of the run above left them.  Every response field bit for bit as from
+        // the single context — through each way a block can travel (written in place / device copy + event / page-locked bounce).
+        std::vector<double> plen(n, 0.0), phead(n, 0.0);
+        std::vector<uint8_t> ach_in(n, 1);
+        for (int32_t i = 0; i < n; ++i) {
+            const auto &p = res_->frontier_list[i];
+            if (black[i] || !p->isAchievable()) continue;
+            plen[i] = p->getPathLength(); phead[i] = p->getPathHeading();
+        }
+        for (const int mode : {0, 3, 2}) {
+            sharded.setOption("multi.gather", (double)mode);
+            std::vector<FrontierPtr> fresh;
+            for (int32_t i = 0; i < n; ++i) {
+                auto fr = std::make_shared<Frontier>();
+                fr->setUID((size_t)i + 1); fr->setSize(sizes[i]); fr->setGoalPoint(goals[2 * i], goals[2 * i + 1]);
+                fresh.push_back(fr);
+            }
+            sharded.assignCosts(fresh, black, ach_in, plen, phead, 0.10, 1.04);
+            int bad2 = sharded.gatherMode() == (mode ? mode : 1) ? 0 : 1;
+            for (int32_t i = 0; i < n; ++i) {
+                const auto &p = res_->frontier_list[i];
+                const auto &q = fresh[i];
+                bad2 += q->getWeightedCost() != res_->frontier_costs[i];
+                if (black[i]) continue;
+                bad2 += q->getArrivalInformation() != res_->frontier_arrival_information[i];
+                bad2 += q->isAchievable() != p->isAchievable();
+                bad2 += q->getGoalYaw() != p->getGoalYaw();
+                bad2 += q->getCost("arrival_gain_utility") != p->getCost("arrival_gain_utility");
+                bad2 += q->getCost("distance_utility") != p->getCost("distance_utility");
+            }
+            printf("ShardedScorer::assignCosts (multi.gather %d): %d mismatches against the single context\n", mode, bad2);
+            if (bad2) ++failures;
+        }
+        std::vector<float> info2;
+        sharded.poseInformation(poses, info2);
+        int bad3 = 0;
+        for (int32_t i = 0; i < n; ++i) bad3 += std::fabs(info2[i] - info[i]) > 2e-6f * std::max(1.0f, std::fabs(info[i]));
+        printf("ShardedScorer::poseInformation: %d mismatches against the single context\n", bad3);
+        if (bad3) ++failures;
     }
 
     // error behaviour of the reference interface
