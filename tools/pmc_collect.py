@@ -118,88 +118,9 @@ def averages(rows, last=6):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc_r03"))
-    ap.add_argument("--workload", default="C3")
-    ap.add_argument("--depth-cells", type=int, default=0)
-    ap.add_argument("--skip-calib", action="store_true")
-    ap.add_argument("--skip-stats", action="store_true")
-    ap.add_argument("--passes", default=",".join(SQ_PASSES))
-    ap.add_argument("--bench-arg", action="append", default=[], help="extra argument for bench.py (repeatable), e.g. --bench-arg=--option --bench-arg=ray.layout=2")
-    args = ap.parse_args()
-    out = os.path.abspath(args.out)
-    os.makedirs(out, exist_ok=True)
-    have = available_counters(out)
-    # The profiled program is the interpreter itself, by its real path: rocprofv3's preloaded library initialises the GPU before
-    # the program starts, so a PATH shim or wrapper (pyenv ...) would be an exec hop behind an initialised GPU.  For the same
-    # reason bench.py must stay a single process here: --gpus N > 1 would make it a launcher that spawns ranks under the profiler.
-    bad = [a for i, a in enumerate(args.bench_arg) if a.startswith("--gpus") and (a not in ("--gpus", "--gpus=1") or (a == "--gpus" and args.bench_arg[i + 1:i + 2] != ["1"]))]
-    if bad:
-        raise SystemExit("pmc_collect.py profiles one process: --gpus other than 1 is refused (profile the rank program, not the launcher)")
-    bench = [os.path.realpath(sys.executable), os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--cpu-seconds", "0", "--no-parity"]
-    if args.depth_cells:
-        bench += ["--depth-cells", str(args.depth_cells)]
-    bench += args.bench_arg
-    fim_angle = 1.0
-    for i, arg in enumerate(args.bench_arg):
-        if arg == "--fim-angle" and i + 1 < len(args.bench_arg):
-            fim_angle = float(args.bench_arg[i + 1])
-        elif arg.startswith("--fim-angle="):
-            fim_angle = float(arg.split("=", 1)[1])
-    summary = {"source_hash": source_hash(), "workload": args.workload, "depth_cells": args.depth_cells, "fim_angle": fim_angle,
-               "collected_with": "tools/pmc_collect.py: rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- "
-                                 "python3 bench.py --steps 3 --warmup 2 --repeats 2 --cpu-seconds 0 --no-parity; means over the last 6 dispatches",
-               "counters_missing": []}
-
-    if not args.skip_stats:
-        d = os.path.join(out, "stats")
-        shutil.rmtree(d, ignore_errors=True)
-        run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", *bench, "--steps", "20", "--warmup", "5", "--repeats", "5"],
-            os.path.join(out, "stats.log"), 600)
-        for f in glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True):
-            shutil.copy(f, os.path.join(out, "kernel_stats.csv"))
-        bl = [ln for ln in open(os.path.join(out, "stats.log")) if ln.startswith("{") and '"metric"' in ln]
-        if bl:
-            open(os.path.join(out, "bench_under_rocprof.json"), "w").write(bl[-1])
-
-    per_kernel = collections.defaultdict(dict)
-    for name in args.passes.split(","):
-        ctrs = [c for c in SQ_PASSES[name] if c in have]
-        summary["counters_missing"] += [c for c in SQ_PASSES[name] if c not in have]
-        if not ctrs:
-            continue
-        d = os.path.join(out, f"pass_{name}")
-        shutil.rmtree(d, ignore_errors=True)
-        rc = run(["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", *bench, "--steps", "3", "--warmup", "2", "--repeats", "2"],
-                 os.path.join(out, f"pass_{name}.log"), 600)
-        if rc != 0:
-            summary.setdefault("failed_passes", []).append(name)
-            continue
-        rows = collect_rows(d, os.path.join(out, f"pmc_{name}.csv"))
-        for k, v in averages(rows).items():
-            per_kernel[k].update(v)
-        shutil.rmtree(d, ignore_errors=True)
-
-    calib = {}
-    exe = os.path.join(ROOT, "tools", "valu_calib")
-    if not args.skip_calib and os.path.exists(exe):
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
-        open(os.path.join(out, "calib_stdout.jsonl"), "w").write(r.stdout + r.stderr)
-        calib["s_memtime"] = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{\"waves")]
-        ck = collections.defaultdict(dict)
-        for name, ctrs in CALIB_PASSES.items():
-            ctrs = [c for c in ctrs if c in have]
-            d = os.path.join(out, f"calib_{name}")
-            shutil.rmtree(d, ignore_errors=True)
-            rc = run(["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", exe], os.path.join(out, f"calib_{name}.log"), 300)
-            if rc == 0:
-                rows = collect_rows(d, os.path.join(out, f"pmc_calib_{name}.csv"))
-                for k, v in averages(rows, last=1).items():      # the second (timed) launch of each configuration
-                    ck[k].update(v)
-            shutil.rmtree(d, ignore_errors=True)
-        calib["counters"] = ck
-
+def derive(summary, per_kernel, calib):
+    """The figures bench.py replays, from the per-kernel counter means and the VALU calibration (pure arithmetic: also run by
+    --rederive on a summary collected with --skip-calib, with the calibration of another collection of the same box)."""
     # ---- derived figures
     summary["kernels"] = per_kernel
     summary["calibration"] = calib
@@ -271,6 +192,103 @@ def main():
                 + (f", L2 hit rate {res['l2_hit_rate']:.1%}" if "l2_hit_rate" in res else "")
                 + (f", HBM traffic {hbm / 1e6:.1f} MB per launch = {hbm / (dur * 1e-6) / 1e9:.0f} GB/s of 8000" if hbm and dur else "")
                 + ": not HBM-bound")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc_r03"))
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--depth-cells", type=int, default=0)
+    ap.add_argument("--skip-calib", action="store_true")
+    ap.add_argument("--skip-stats", action="store_true")
+    ap.add_argument("--passes", default=",".join(SQ_PASSES))
+    ap.add_argument("--rederive", default="", help="no GPU work: recompute the derived figures of <dir>/pmc_summary.json (collected with --skip-calib) with the calibration of --calib-from")
+    ap.add_argument("--calib-from", default="", help="a pmc_summary.json whose `calibration` block to use with --rederive (same box, same session)")
+    ap.add_argument("--bench-arg", action="append", default=[], help="extra argument for bench.py (repeatable), e.g. --bench-arg=--option --bench-arg=ray.layout=2")
+    args = ap.parse_args()
+    if args.rederive:
+        path = os.path.join(args.rederive, "pmc_summary.json")
+        summary = json.load(open(path))
+        calib = json.load(open(args.calib_from))["calibration"]
+        summary["calibration"] = calib
+        summary["calibration_from"] = "the collection " + os.path.basename(os.path.dirname(os.path.abspath(args.calib_from))) + " of the same gpurun session (this one ran with --skip-calib)"
+        derive(summary, summary["kernels"], calib)
+        json.dump(summary, open(path, "w"), indent=1, sort_keys=True, default=dict)
+        print(json.dumps({k: summary.get(k) for k in ("source_hash", "fim_angle", "bound", "valu_issue_utilisation", "bound_evidence")}, indent=1))
+        return
+    out = os.path.abspath(args.out)
+    os.makedirs(out, exist_ok=True)
+    have = available_counters(out)
+    # The profiled program is the interpreter itself, by its real path: rocprofv3's preloaded library initialises the GPU before
+    # the program starts, so a PATH shim or wrapper (pyenv ...) would be an exec hop behind an initialised GPU.  For the same
+    # reason bench.py must stay a single process here: --gpus N > 1 would make it a launcher that spawns ranks under the profiler.
+    bad = [a for i, a in enumerate(args.bench_arg) if a.startswith("--gpus") and (a not in ("--gpus", "--gpus=1") or (a == "--gpus" and args.bench_arg[i + 1:i + 2] != ["1"]))]
+    if bad:
+        raise SystemExit("pmc_collect.py profiles one process: --gpus other than 1 is refused (profile the rank program, not the launcher)")
+    bench = [os.path.realpath(sys.executable), os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--cpu-seconds", "0", "--no-parity"]
+    if args.depth_cells:
+        bench += ["--depth-cells", str(args.depth_cells)]
+    bench += args.bench_arg
+    fim_angle = 1.0
+    for i, arg in enumerate(args.bench_arg):
+        if arg == "--fim-angle" and i + 1 < len(args.bench_arg):
+            fim_angle = float(args.bench_arg[i + 1])
+        elif arg.startswith("--fim-angle="):
+            fim_angle = float(arg.split("=", 1)[1])
+    summary = {"source_hash": source_hash(), "workload": args.workload, "depth_cells": args.depth_cells, "fim_angle": fim_angle,
+               "collected_with": "tools/pmc_collect.py: rocprofv3 --pmc <one counter set per pass> --kernel-trace --output-format csv -- "
+                                 "python3 bench.py --steps 3 --warmup 2 --repeats 2 --cpu-seconds 0 --no-parity; means over the last 6 dispatches",
+               "counters_missing": []}
+
+    if not args.skip_stats:
+        d = os.path.join(out, "stats")
+        shutil.rmtree(d, ignore_errors=True)
+        run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "--", *bench, "--steps", "20", "--warmup", "5", "--repeats", "5"],
+            os.path.join(out, "stats.log"), 600)
+        for f in glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(out, "kernel_stats.csv"))
+        bl = [ln for ln in open(os.path.join(out, "stats.log")) if ln.startswith("{") and '"metric"' in ln]
+        if bl:
+            open(os.path.join(out, "bench_under_rocprof.json"), "w").write(bl[-1])
+
+    per_kernel = collections.defaultdict(dict)
+    for name in args.passes.split(","):
+        ctrs = [c for c in SQ_PASSES[name] if c in have]
+        summary["counters_missing"] += [c for c in SQ_PASSES[name] if c not in have]
+        if not ctrs:
+            continue
+        d = os.path.join(out, f"pass_{name}")
+        shutil.rmtree(d, ignore_errors=True)
+        rc = run(["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", *bench, "--steps", "3", "--warmup", "2", "--repeats", "2", "--min-timed-seconds", "0"],
+                 os.path.join(out, f"pass_{name}.log"), 600)
+        if rc != 0:
+            summary.setdefault("failed_passes", []).append(name)
+            continue
+        rows = collect_rows(d, os.path.join(out, f"pmc_{name}.csv"))
+        for k, v in averages(rows).items():
+            per_kernel[k].update(v)
+        shutil.rmtree(d, ignore_errors=True)
+
+    calib = {}
+    exe = os.path.join(ROOT, "tools", "valu_calib")
+    if not args.skip_calib and os.path.exists(exe):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        open(os.path.join(out, "calib_stdout.jsonl"), "w").write(r.stdout + r.stderr)
+        calib["s_memtime"] = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{\"waves")]
+        ck = collections.defaultdict(dict)
+        for name, ctrs in CALIB_PASSES.items():
+            ctrs = [c for c in ctrs if c in have]
+            d = os.path.join(out, f"calib_{name}")
+            shutil.rmtree(d, ignore_errors=True)
+            rc = run(["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "--output-format", "csv", "-d", d, "--", exe], os.path.join(out, f"calib_{name}.log"), 300)
+            if rc == 0:
+                rows = collect_rows(d, os.path.join(out, f"pmc_calib_{name}.csv"))
+                for k, v in averages(rows, last=1).items():      # the second (timed) launch of each configuration
+                    ck[k].update(v)
+            shutil.rmtree(d, ignore_errors=True)
+        calib["counters"] = ck
+
+    derive(summary, per_kernel, calib)
     json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1, sort_keys=True, default=dict)
     print(json.dumps({k: summary.get(k) for k in ("source_hash", "valu_peak_wave_insts_per_cycle_per_simd", "valu_issue_utilisation", "fs_fim_kernel",
                                                  "fs_fim_kernel_hbm_bytes_per_launch", "counters_missing", "failed_passes")}, indent=1, default=dict))
