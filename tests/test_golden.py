@@ -20,7 +20,7 @@ def _params(z):
 
 
 def test_fixtures_exist():
-    assert len(GOLDEN) >= 2
+    assert len(GOLDEN) >= 3
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
@@ -34,10 +34,17 @@ def test_oracle_reproduces_golden(oracle, ref_table, path):
     for k in INT_KEYS:
         np.testing.assert_array_equal(arr[k], z[k], err_msg=k)
     np.testing.assert_array_equal(arr["yaw"], z["yaw"])
-    fim = oracle.pose_information(ref_table, z["landmarks"], oracle.poses_from_yaw(z["goals"], arr["yaw"]), 14.0, 1.0)
+    fim = oracle.pose_information(ref_table, z["landmarks"], oracle.poses_from_yaw(z["goals"], arr["yaw"]), 14.0, float(z["max_angle"]))
     np.testing.assert_array_equal(fim["n_visible"], z["n_visible"])
     np.testing.assert_array_equal(fim["n_voxels"], z["n_voxels"])
     np.testing.assert_array_equal(fim["info_ref"], z["info_ref"])
+    np.testing.assert_array_equal(fim["logdet"], z["logdet"])
+    rc, u1 = oracle.u1_costs(arr["arrival"].astype(np.float64), arr["achievable"], z["path_length"], z["path_heading"],
+                             float(z["max_gt_for_costs"]), blacklisted=z["blacklisted"])
+    assert rc == 0
+    for k in ("weighted_cost", "arrival_utility", "distance_utility"):
+        np.testing.assert_array_equal(u1[k], z[k], err_msg=k)
+    np.testing.assert_array_equal(np.argsort(u1["weighted_cost"], kind="stable"), z["order"])
 
 
 @pytest.mark.gpu
@@ -47,7 +54,7 @@ def test_hip_reproduces_golden(fs, scorer, path):
     scorer.set_ray_params(**_params(z))
     scorer.upload_grid(z["cells"], tuple(z["origin"]), float(z["resolution"]))
     scorer.upload_landmarks(z["landmarks"])
-    scorer.set_fim_params(14.0, 1.0)
+    scorer.set_fim_params(14.0, float(z["max_angle"]))
     mx = scorer.max_arrival()
     assert (mx["max_value"], mx["max_gt"], mx["min_gt"]) == (float(z["max_value"]), float(z["max_gt"]), float(z["min_gt"]))
     arr = scorer.score_arrival(z["goals"], z["frontier_size"], z["blacklisted"])
@@ -62,3 +69,21 @@ def test_hip_reproduces_golden(fs, scorer, path):
     sc = np.maximum(np.abs(z["info_f64"][ok]), 1e-6)
     assert np.max(np.abs(rec["info_ref"][ok] - z["info_f64"][ok]) / sc) <= 1e-4
     assert np.max(np.abs(rec["trace"][ok] - z["trace"][ok]) / np.maximum(z["trace"][ok], 1e-6)) <= 1e-4
+    import importlib
+    gate = importlib.import_module("fit-slam_amd.parity").logdet_gate(rec["logdet"], z["logdet"], z["fim"], consider=ok, n_visible=z["n_visible"])
+    assert gate["ok"], gate
+    # the whole cost assignment as one call (fs_get_frontier_costs, Fisher information included) against the fixture's U1 block
+    scorer.set_arrival_limits(float(z["max_gt_for_costs"]), float(z["min_gt"]))
+    try:
+        got = scorer.get_frontier_costs(z["goals"], z["path_length"], z["path_heading"], z["frontier_size"], z["blacklisted"], with_fim=True)
+    finally:
+        scorer.set_arrival_limits(mx["max_gt"], mx["min_gt"])
+    np.testing.assert_array_equal(got["records"]["arrival"], z["arrival"])
+    np.testing.assert_array_equal(got["records"]["n_visible"][ok], z["n_visible"][ok])
+    for k in ("weighted_cost", "arrival_utility", "distance_utility", "order"):
+        np.testing.assert_array_equal(got[k], z[k], err_msg=k)
+    # and the info-only call (isPoseSafe's) on the fixture's poses
+    poses = fs.synth.poses_from_yaw(z["goals"], z["yaw"])
+    io = scorer.score_fim(poses, info_only=True)
+    np.testing.assert_array_equal(io["n_voxels"][ok], z["n_voxels"][ok])
+    assert np.max(np.abs(io["info_ref"][ok] - z["info_f64"][ok]) / sc) <= 1e-4
