@@ -6,8 +6,9 @@
 //   u = alpha * (arrival / max_arrival_gt) + (1 - alpha) * (1 - (len/vmax + heading/wmax) / (maxlen/vmax + pi/wmax)),
 //   cost = 1 / (beta * u).
 // All arithmetic is fp64 with the reference's operation order (basic IEEE ops only), so costs match
-// the CPU bit for bit.  Ranking = stable ascending sort by cost (rocPRIM radix sort on the
-// order-preserving integer image of the double).
+// the CPU bit for bit.  Ranking = stable ascending sort by cost: rocPRIM's radix sort on the order-preserving integer image
+// of the double for long lists; for lists of up to 1024 candidates (the reference's operating point) ONE workgroup does the
+// normalisation, the costs and a bitonic sort of (cost image, index) pairs in LDS in one launch.
 #include "fs_internal.h"
 
 #include <algorithm>
@@ -90,6 +91,30 @@ __device__ __forceinline__ uint64_t sortable(double v)
     return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// One candidate's U1 utilities and weighted cost (FrontierCostsManager.cpp:126-205) — ONE definition for the list kernel and the
+// small-list kernel below, so that both give the same bits.  Returns true where the reference throws ("Cost out of bounds").
+__device__ __forceinline__ bool u1_cost(bool live, double arrival, double len, double head, double max_d, double min_d, double min_i,
+                                        double alpha, double beta, double max_vx, double max_wz, double max_gt,
+                                        double &c, double &au, double &pu)
+{
+    const double PI = 3.14159265358979323846;
+    if (!live) {
+        // FrontierCostsManager.cpp:84 (blacklisted) / :129-135 (not achievable)
+        c = FS_DBL_MAX; au = -69.8; pu = -1.8;
+        return false;
+    }
+    if ((double)(max_gt - min_i) == 0.0) au = 0.0;                                  // :139-140
+    else au = arrival / (double)max_gt;                                               // :145-146
+    if ((double)((max_d / max_vx + PI / max_wz) - (min_d / max_vx + 0.0 / max_wz) == 0.0)) pu = 1.0;   // :152-153
+    else pu = (double)(len / max_vx + head / max_wz) / (double)(max_d / max_vx + PI / max_wz);           // :158-159
+    pu = 1.0 - pu;                                                                    // :160
+    const bool out_of_bounds = au > 1.0 || au < 0.0 || pu > 1.0 || pu < 0.0;          // :148-149,173-174
+    double utility = (alpha * au) + ((1.0 - alpha) * pu);                             // :176-177
+    if (utility == 0.0) utility = 1e-16;                                              // :178-182
+    c = 1 / (beta * utility);                                                         // :198
+    return out_of_bounds;
+}
+
 __global__ void fs_rank_cost_kernel(int32_t n, const fs_record *rec, const uint8_t *black, const double *len,
                                     const double *head, const RankNorm *norm, double alpha, double beta,
                                     double max_vx, double max_wz, double max_gt,
@@ -98,27 +123,73 @@ __global__ void fs_rank_cost_kernel(int32_t n, const fs_record *rec, const uint8
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double PI = 3.14159265358979323846;
     double c, au, pu;
-    const bool bl = black && black[i];
-    if (bl || !(rec[i].flags & FS_FLAG_ACHIEVABLE)) {
-        // FrontierCostsManager.cpp:84 (blacklisted) / :129-135 (not achievable)
-        c = FS_DBL_MAX; au = -69.8; pu = -1.8;
-    } else {
-        const double max_d = norm->max_dist, min_d = norm->min_dist, min_i = norm->min_info;
-        if ((double)(max_gt - min_i) == 0.0) au = 0.0;                                  // :139-140
-        else au = (double)rec[i].arrival / (double)max_gt;                                // :145-146
-        if ((double)((max_d / max_vx + PI / max_wz) - (min_d / max_vx + 0.0 / max_wz) == 0.0)) pu = 1.0;   // :152-153
-        else pu = (double)(len[i] / max_vx + head[i] / max_wz) / (double)(max_d / max_vx + PI / max_wz);     // :158-159
-        pu = 1.0 - pu;                                                                    // :160
-        if (au > 1.0 || au < 0.0 || pu > 1.0 || pu < 0.0) atomicOr(err, 1);              // :148-149,173-174
-        double utility = (alpha * au) + ((1.0 - alpha) * pu);                             // :176-177
-        if (utility == 0.0) utility = 1e-16;                                              // :178-182
-        c = 1 / (beta * utility);                                                         // :198
-    }
+    const bool live = !(black && black[i]) && (rec[i].flags & FS_FLAG_ACHIEVABLE);
+    if (u1_cost(live, (double)rec[i].arrival, live ? len[i] : 0.0, live ? head[i] : 0.0, norm->max_dist, norm->min_dist, norm->min_info,
+                alpha, beta, max_vx, max_wz, max_gt, c, au, pu))
+        atomicOr(err, 1);
     cost[i] = c; au_out[i] = au; du_out[i] = pu;
     keys[i] = sortable(c);
     vals[i] = i;
+}
+
+// The whole ranking of a SHORT list — the reference handles tens of frontiers per tick — in ONE launch of ONE workgroup:
+// normalisation factors (block reduction), U1 costs, and the stable ascending order by a bitonic network over (cost image,
+// index) pairs in LDS (the index breaks ties, which makes the order the stable one whatever the network does).  Replaces three
+// launches (normalisation, costs, rocPRIM's block sort) for n <= FS_RANK_SMALL_MAX.
+#define FS_RANK_SMALL_MAX 1024
+__global__ __launch_bounds__(FS_RANK_SMALL_MAX)
+void fs_rank_small_kernel(int32_t n, const fs_record *rec, const uint8_t *black, const double *len, const double *head,
+                          double alpha, double beta, double max_vx, double max_wz, double max_gt,
+                          double *cost, double *au_out, double *du_out, int32_t *order, int32_t *err)
+{
+    __shared__ uint64_t s_key[FS_RANK_SMALL_MAX];
+    __shared__ int32_t s_idx[FS_RANK_SMALL_MAX];
+    __shared__ double s_min_d[16], s_max_d[16], s_min_i[16];
+    __shared__ int s_err;
+    const int i = threadIdx.x, P = blockDim.x;                 // P: a power of two >= n (and >= 64)
+    const int wave = i >> 6, lane = i & 63;
+    if (i == 0) s_err = 0;
+    bool live = false;
+    double l = 0.0, h = 0.0, a = 0.0;
+    if (i < n) {
+        live = !(black && black[i]) && (rec[i].flags & FS_FLAG_ACHIEVABLE);
+        a = (double)rec[i].arrival;
+        if (live) { l = len[i]; h = head[i]; }
+    }
+    // reset() + recomputeNormalizationFactors over the live candidates (CostCalculator.cpp:512-520)
+    double min_d = live ? l : FS_DBL_MAX, max_d = live ? l : -1.0, min_i = live ? a : FS_DBL_MAX;
+    min_d = wave_min(min_d); max_d = wave_max(max_d); min_i = wave_min(min_i);
+    if (lane == 0) { s_min_d[wave] = min_d; s_max_d[wave] = max_d; s_min_i[wave] = min_i; }
+    __syncthreads();
+    for (int w = 0; w < (P >> 6); ++w) {                       // (every thread folds the <= 16 partials itself: min / max are exact in any order)
+        min_d = (s_min_d[w] < min_d) ? s_min_d[w] : min_d;
+        max_d = (max_d < s_max_d[w]) ? s_max_d[w] : max_d;
+        min_i = (s_min_i[w] < min_i) ? s_min_i[w] : min_i;
+    }
+    uint64_t key = ~0ull;                                       // padding sorts behind every candidate
+    if (i < n) {
+        double c, au, pu;
+        if (u1_cost(live, a, l, h, max_d, min_d, min_i, alpha, beta, max_vx, max_wz, max_gt, c, au, pu)) atomicOr(&s_err, 1);
+        cost[i] = c; au_out[i] = au; du_out[i] = pu;
+        key = sortable(c);
+    }
+    s_key[i] = key; s_idx[i] = i;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int p = i ^ j;
+            if (p > i) {
+                const uint64_t ka = s_key[i], kb = s_key[p];
+                const int32_t ia = s_idx[i], ib = s_idx[p];
+                const bool a_after_b = ka > kb || (ka == kb && ia > ib);
+                if (a_after_b == ((i & k) == 0)) { s_key[i] = kb; s_key[p] = ka; s_idx[i] = ib; s_idx[p] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    if (i < n) order[i] = s_idx[i];
+    if (i == 0) *err = s_err;
 }
 
 }  // namespace
@@ -129,6 +200,13 @@ hipError_t fs_launch_rank(int32_t n, const fs_record *d_records, const uint8_t *
                           double *d_du, int32_t *d_order, int32_t *d_err, void **scratch, size_t *scratch_bytes,
                           hipStream_t s)
 {
+    if (n <= FS_RANK_SMALL_MAX) {
+        int threads = 64;
+        while (threads < n) threads <<= 1;
+        hipLaunchKernelGGL(fs_rank_small_kernel, dim3(1), dim3(threads), 0, s, n, d_records, d_black, d_len, d_head, alpha, beta, max_vx, max_wz,
+                           max_gt, d_cost, d_au, d_du, d_order, d_err);
+        return hipGetLastError();
+    }
     size_t temp_bytes = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, temp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
                                              (int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, 0, 64, s);

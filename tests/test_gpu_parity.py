@@ -707,11 +707,12 @@ def test_fim_table_with_holes(fs, oracle, scorer, ref_table):
         scorer.lookup_generate()
 
 
-@pytest.mark.parametrize("n", [1, 255, 256, 257, 1023, 1024, 1025, 5000, 32768, 32769, 70000])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 5000, 32768, 32769, 70000])
 def test_rank_order_is_the_stable_ascending_sort_at_every_size(fs, oracle, scorer, n):
-    """Up to 32 768 candidates the order comes from ONE all-pairs counting kernel (fs_rank_order_kernel), beyond from rocPRIM's
-    sort: both must be numpy's stable argsort of the (bit-exact) costs — with thousands of equal costs (the unachievable and
-    blacklisted candidates all carry DBL_MAX, and quantised path lengths make ties among the live ones)."""
+    """Up to 1024 candidates ONE workgroup ranks the list in one launch (fs_rank_small_kernel: normalisation, costs, a bitonic
+    network over (cost image, index) pairs in LDS), beyond that rocPRIM's sort: both must be numpy's stable argsort of the
+    (bit-exact) costs — with thousands of equal costs (the unachievable and blacklisted candidates all carry DBL_MAX, and quantised
+    path lengths make ties among the live ones)."""
     rng = np.random.default_rng(n)
     rec = np.zeros(n, dtype=fs.capi.RECORD_DTYPE)
     rec["arrival"] = rng.integers(0, 400, size=n)
