@@ -224,7 +224,6 @@ struct fs_ctx {
     bool opt_costmap = true;       // the spatial sort puts the blocks that were expensive in the previous call first ("sort.costmap")
     const uint32_t *sort_keys = nullptr;   // this call's sort keys / the cost map inside sort_scratch (nullptr: list not sorted)
     uint32_t *sort_costmap = nullptr;
-    int opt_ray_small = 512;       // "ray.small": lists up to this many candidates walk with 16 cell loads in flight per lane (0: never)
     int opt_layout = 0;            // "ray.layout": 0 by ray length, 1 row-major byte walk, 2 class-image walk, 3 sparse class image (experiment)
 
     // launch graphs of the small host-buffer calls ("graph" option; off while kernel timing is on)
@@ -1135,8 +1134,6 @@ int fs_max_arrival(fs_ctx *c, double *max_value, double *max_gt, double *min_gt)
 // Spatial processing order for the ray-march kernel (outputs stay in list order).  Small lists are not worth a sort.
 static int maybe_sort(fs_ctx *c, FsRayArgs &a)
 {
-    // (every fan launch passes through here with its list length known: short lists take the deep-speculation kernel)
-    a.unroll_small = (c->opt_ray_small > 0 && a.n <= c->opt_ray_small) ? 1 : 0;
     a.perm = nullptr;
     c->sort_keys = nullptr; c->sort_costmap = nullptr;
     if (!c->opt_sort || a.n < 2048) return FS_OK;
@@ -1450,7 +1447,6 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.split") == 0 && value >= 0 && value <= 5) { c->opt_split = (int)value; ++c->epoch; return FS_OK; }
-    if (std::strcmp(key, "ray.small") == 0 && value >= 0) { c->opt_ray_small = (int)value; ++c->epoch; return FS_OK; }
     if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 3) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.skip32") == 0 && value >= 1 && value <= 32) { c->opt_skip32 = (int)value; return FS_OK; }

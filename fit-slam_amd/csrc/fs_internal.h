@@ -60,7 +60,6 @@ struct FsRayArgs {
     int32_t obst_min, obst_max, trace_min, trace_max;
     int32_t clamp;             // CostCalculator.cpp:47-48 (1) or setMaxArrivalInformation (0)
     int32_t layout;            // 0: row-major byte image (WalkLinear), 1: class image (WalkClass), 2: sparse class image (WalkSparse)
-    int32_t unroll_small;      // 1: the list is short — the kernel instantiation with 16 instead of 4 cell loads in flight per lane
     double lo_x, hi_x, lo_y, hi_y, lo_z, hi_z;   // folded clamp bounds: max(poly_min, origin), min(poly_max, origin + sizeInMeters)
     double footprint_radius;   // ceil(robot_radius / resolution)
     double delta_theta, half_fov;

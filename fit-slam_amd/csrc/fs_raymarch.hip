@@ -21,7 +21,6 @@
 #ifndef FS_RAY_UNROLL
 #define FS_RAY_UNROLL 4         // speculative cell loads in flight per lane
 #endif
-#define FS_RAY_UNROLL_SMALL 16  // ... for short lists (latency, not throughput: see ray_march)
 
 namespace {
 
@@ -263,11 +262,7 @@ __device__ __forceinline__ bool ray_setup(const FsRayArgs &a, bool start_ok, uin
 
 // RayTracedCells over the walk: number of cells in [trace_min,trace_max] seen before the first
 // cell in [obst_min,obst_max]  (= cells_.size(), DEP/src/CostCalculator.cpp:57-58).
-// U: speculative cell loads in flight per lane.  The walk's ADDRESSES never depend on what the cells hold (only the early exit
-// does), so any number of visits may be requested at once: FS_RAY_UNROLL (4) is the measured optimum for throughput, where
-// thousands of fans hide each other's latency; a call with a handful of fans is one chain of dependent memory round trips —
-// eleven of them for a 41-visit ray at U = 4, three at U = 16 (FS_RAY_UNROLL_SMALL, chosen by the launcher for short lists).
-template <int U, typename Walk>
+template <typename Walk>
 __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
 {
     // the visitor's inclusive ranges, intersected with the byte range of a cell, as one unsigned compare each; an empty
@@ -278,34 +273,34 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
     const uint32_t orange = o_any ? (uint32_t)(omax - omin) : 0u, trange = t_any ? (uint32_t)(tmax - tmin) : 0u;
     int count = 0;
     uint32_t visits = w.end + 1;          // loop visits + the one after the loop (Helpers.cpp:29)
-    // full groups of U visits first: every visit of the group exists, so the loads and steps need no per-step
-    // bounds (one exec mask per group instead of one per step); the remainder (< U visits) goes through the guarded
+    // full groups of FS_RAY_UNROLL visits first: every visit of the group exists, so the loads and steps need no per-step
+    // bounds (one exec mask per group instead of one per step); the remainder (< FS_RAY_UNROLL visits) goes through the guarded
     // loop below.  Loads past an obstacle are speculative but always inside the start/end bounding box, hence in the grid.
     bool stopped = false;
-    while (visits >= U) {
-        int c[U];
+    while (visits >= FS_RAY_UNROLL) {
+        int c[FS_RAY_UNROLL];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
             c[u] = walk_cell(a.grid, w);
             walk_step(w);                   // (the step behind a ray's very last visit leads nowhere that is read)
         }
         bool hit = false;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
             const bool traced = t_any && !hit && (uint32_t)(c[u] - tmin) <= trange;
             count += traced ? 1 : 0;
             hit = hit || (o_any && (uint32_t)(c[u] - omin) <= orange);
         }
         if (hit) { stopped = true; break; }  // nothing is pushed after the first obstacle
-        visits -= U;
+        visits -= FS_RAY_UNROLL;
     }
     if (stopped) visits = 0;
     while (visits > 0) {
-        // the last, partial group: up to U - 1 independent byte loads, then classify them in order
-        int c[U];
-        const uint32_t nb = visits < U ? visits : U;
+        // the last, partial group: up to FS_RAY_UNROLL - 1 independent byte loads, then classify them in order
+        int c[FS_RAY_UNROLL];
+        const uint32_t nb = visits < FS_RAY_UNROLL ? visits : FS_RAY_UNROLL;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
             c[u] = -1;
             if ((uint32_t)u < nb) {
                 c[u] = walk_cell(a.grid, w);
@@ -317,7 +312,7 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
         // when the two ranges overlap); slots past `nb` hold -1 and match no range
         bool hit = false;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
             const bool traced = t_any && !hit && (uint32_t)(c[u] - tmin) <= trange;
             count += traced ? 1 : 0;
             hit = hit || (o_any && (uint32_t)(c[u] - omin) <= orange);
@@ -331,33 +326,33 @@ __device__ __forceinline__ int ray_march(const FsRayArgs &a, Walk w)
 // The visitor over the class image (the classes were cut with this launch's ranges: fs_capi.hip keeps them in step): bit 0
 // counts while no earlier cell of the ray carried bit 1 (Helpers.hpp:64-71 — the traced test comes before hit_obstacle is set,
 // so a cell in both ranges still counts).
-template <int U, typename W>
+template <typename W>
 __device__ __forceinline__ int ray_march_classes(const FsRayArgs &a, W w)
 {
     int count = 0;
     uint32_t visits = w.end + 1;
     uint32_t open = 1u;                              // 1 until the first obstacle
-    while (visits >= U) {
-        uint32_t c[U];
+    while (visits >= FS_RAY_UNROLL) {
+        uint32_t c[FS_RAY_UNROLL];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
             c[u] = walk_class(a.grid, w);
             walk_step(w);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL; ++u) {
             count += (int)(c[u] & open);
             open &= ~(c[u] >> 1);
         }
         if (!open) return count;
-        visits -= U;
+        visits -= FS_RAY_UNROLL;
     }
     if (visits > 0) {
         // the last, partial group as ONE batch of independent loads (a loop of single visits would expose a load latency
         // per step); slots past the ray's end hold class 0, which neither counts nor stops
-        uint32_t c[U - 1];
+        uint32_t c[FS_RAY_UNROLL - 1];
 #pragma unroll
-        for (int u = 0; u < U - 1; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL - 1; ++u) {
             c[u] = 0u;
             if ((uint32_t)u < visits) {
                 c[u] = walk_class(a.grid, w);
@@ -365,7 +360,7 @@ __device__ __forceinline__ int ray_march_classes(const FsRayArgs &a, W w)
             }
         }
 #pragma unroll
-        for (int u = 0; u < U - 1; ++u) {
+        for (int u = 0; u < FS_RAY_UNROLL - 1; ++u) {
             count += (int)(c[u] & open);
             open &= ~(c[u] >> 1);
         }
@@ -373,8 +368,8 @@ __device__ __forceinline__ int ray_march_classes(const FsRayArgs &a, W w)
     return count;
 }
 
-template <int U> __device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkClass w) { return ray_march_classes<U>(a, w); }
-template <int U> __device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkSparse w) { return ray_march_classes<U>(a, w); }
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkClass w) { return ray_march_classes(a, w); }
+__device__ __forceinline__ int ray_march(const FsRayArgs &a, WalkSparse w) { return ray_march_classes(a, w); }
 
 // Every wave of the kernel below works on LDS of its own (per-yaw sums, tile, descriptors): what it wrote must be visible to
 // its own later reads — which the LDS guarantees per wave, in program order — so the points where that matters need the
@@ -391,7 +386,7 @@ __device__ __forceinline__ void wave_lds_fence()
 #else
 #define FS_RAY_OCCUPANCY
 #endif
-template <typename Walk, int U = FS_RAY_UNROLL>
+template <typename Walk>
 __global__ __launch_bounds__(FS_RAY_WAVES * 64) FS_RAY_OCCUPANCY
 void fs_raymarch_kernel(const FsRayArgs a)
 {
@@ -437,7 +432,7 @@ void fs_raymarch_kernel(const FsRayArgs a)
             }
             Walk w;
             int count = 0;
-            if (ray_setup(a, start_ok, sxm, sym, szm, wx, wy, wz, w)) count = ray_march<U>(a, w);
+            if (ray_setup(a, start_ok, sxm, sym, szm, wx, wy, wz, w)) count = ray_march(a, w);
             else fail = true;
             if (count) atomicAdd(&ysum[i], count);
             if (a.ray_counts) a.ray_counts[(size_t)c * n_rays + r] = count;
@@ -579,12 +574,8 @@ hipError_t fs_launch_raymarch(const FsRayArgs &a, hipStream_t s)
     int blocks = (a.n + FS_RAY_WAVES - 1) / FS_RAY_WAVES;
     if (a.perm) blocks = (blocks + 7) / 8 * 8;               // whole XCD rounds for the remap above
     const size_t lds = sizeof(int) * (size_t)FS_RAY_WAVES * (size_t)a.n_yaw;
-    // a short list is a chain of dependent memory round trips per fan, not a throughput problem: four times the loads in flight
-    const bool small = a.unroll_small != 0;
     if (a.layout == 2) hipLaunchKernelGGL(fs_raymarch_kernel<WalkSparse>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
-    else if (a.layout == 1 && small) hipLaunchKernelGGL((fs_raymarch_kernel<WalkClass, FS_RAY_UNROLL_SMALL>), dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else if (a.layout == 1) hipLaunchKernelGGL(fs_raymarch_kernel<WalkClass>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
-    else if (small) hipLaunchKernelGGL((fs_raymarch_kernel<WalkLinear, FS_RAY_UNROLL_SMALL>), dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     else hipLaunchKernelGGL(fs_raymarch_kernel<WalkLinear>, dim3(blocks), dim3(FS_RAY_WAVES * 64), lds, s, a);
     return hipGetLastError();
 }

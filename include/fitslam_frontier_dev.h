@@ -34,9 +34,6 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * walk (identical results in every case; DESIGN.md 4.1 holds the measured table); 3 = the class image as a brick table + a pool
  * of distinct bricks (BASELINE.json configs[4]'s "sparse" form: 2.6x smaller, half the L2 traffic, 40 % SLOWER — an experiment kept
  * reproducible, profiles/EXPERIMENTS.md).
- * "ray.small" (default 512): lists of up to this many candidates walk with 16 instead of 4 speculative cell loads in flight
- * per lane — a short list is a chain of dependent memory round trips per fan (eleven for a 41-visit ray at 4, three at 16), not a
- * throughput problem; 0 = never.  Identical results.
  * "fim.bits1", "fim.skip32": development knobs of the hash table (size; predicted share of distinct voxels among the
  * landmarks scanned, in 32nds, that decides the number of scoring passes — the cap under which the worker uses what
  * finished calls on the cloud have shown: DESIGN.md 4.2).

@@ -608,9 +608,7 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
             for layout in (1, 2, 3, 0):                            # 1 row-major byte image, 2 class image, 3 sparse class image (brick table + pool), 0 chosen by ray length
                 scorer.set_option("ray.layout", layout)
                 assert scorer.max_arrival() == mx_o
-                for small in (0, 1 << 20):                           # 4 / 16 cell loads in flight per lane (the short-list instantiation)
-                    scorer.set_option("ray.small", small)
-                    _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
+                _assert_arrival_equal(scorer.score_arrival(w.goals, w.frontier_size, w.blacklisted), want)
         # odd sizes: nx, ny not multiples of 8, nz odd
         cells = rng.choice(np.array([0, 0, 0, 255, 255, 254, 250], np.uint8), size=(5, 37, 43))
         origin = (-1.0, -0.9, -0.1)
@@ -632,7 +630,6 @@ def test_grid_layouts_give_identical_walks(fs, oracle, scorer):
                     (r["traced"], r["hit"], r["unknown"], r["all"]), i
     finally:
         scorer.set_option("ray.layout", 0)
-        scorer.set_option("ray.small", 512)
 
 
 def test_class_image_walk_equals_the_row_major_walk(fs, oracle, scorer):
