@@ -437,6 +437,8 @@ int fs_multi_get_frontier_costs(fs_multi *m, int32_t n, const double *goal_xyz, 
         // stream is idle once member 0's has passed its event — waited for here all the same, it costs nothing)
         for (int g : started) (void)fs_synchronize(m->ctx[(size_t)g]);
     }
+    // a call that worked through the bounce says so every time (an earlier failure may have overwritten the note)
+    if (first_error == FS_OK && mode == FS_GATHER_HOST && m->gather_forced == FS_GATHER_AUTO && !m->gather_note.empty()) m->err = m->gather_note;
     return first_error;
 }
 
