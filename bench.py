@@ -367,6 +367,7 @@ def run_latency(args) -> int:
         # the whole cost assignment of a tick as ONE call (fs_get_frontier_costs: arrival information + U1 + order; what the
         # reference's assignCosts computes), path columns as the Euclidean stand-in planner would set them
         res["get_frontier_costs"] = {}
+        fc_by_n = {}
         for n in (50, 200, 2000):
             g, f, b = w.goals[:n], w.frontier_size[:n], w.blacklisted[:n]
             pl = np.hypot(g[:, 0], g[:, 1]) + 0.5
@@ -380,7 +381,35 @@ def run_latency(args) -> int:
                 fc = sc.get_frontier_costs(g, pl, ph, f, b, with_fim=False)
                 ts.append((time.perf_counter() - t0) * 1e6)
             sc.set_arrival_limits(mx["max_gt"], mx["min_gt"])
+            fc_by_n[n] = fc
             res["get_frontier_costs"][str(n)] = dict(_percentiles(ts), order_is_a_permutation=bool(np.array_equal(np.sort(fc["order"]), np.arange(n))))
+        # the same call through the multi-device form on TWO contexts of this one GPU (fs_multi_get_frontier_costs: blocks scored side
+        # by side, gathered on the device, ranked, one transfer out) — what the in-process multi-GPU path adds to a call, by the
+        # way a block travels: 1 = written into the gathered list in place (members of one GPU), 3 = device copy on the member's
+        # stream + event (the machinery a second GPU uses with hipMemcpyPeerAsync), 2 = the page-locked bounce (no peer access).
+        # A rehearsal on one GPU: never a scaling figure.
+        if wl == "REF2D":
+            res["multi_get_frontier_costs_two_contexts_one_gpu"] = {}
+            m = fs.MultiScorer(devices=(0, 0))
+            m.set_ray_params(**kw); m.upload_grid(w.cells, w.origin, w.resolution)
+            m.set_arrival_limits(max(mx["max_gt"], 1000.0) * 4, mx["min_gt"])
+            for mode in (1, 3, 2):
+                m.set_option("multi.gather", mode)
+                for n in (50, 2000):
+                    g, f, b = w.goals[:n], w.frontier_size[:n], w.blacklisted[:n]
+                    pl = np.hypot(g[:, 0], g[:, 1]) + 0.5
+                    ph = np.abs(np.arctan2(g[:, 1], g[:, 0]))
+                    for _ in range(20):
+                        m.get_frontier_costs(g, pl, ph, f, b, with_fim=False)
+                    ts = []
+                    for _ in range(args.latency_calls):
+                        t0 = time.perf_counter()
+                        fm = m.get_frontier_costs(g, pl, ph, f, b, with_fim=False)
+                        ts.append((time.perf_counter() - t0) * 1e6)
+                    res["multi_get_frontier_costs_two_contexts_one_gpu"][f"gather_mode_{mode}_n{n}"] = dict(
+                        _percentiles(ts), equals_one_context=bool(np.array_equal(fm["weighted_cost"], fc_by_n[n]["weighted_cost"]) and
+                                                                  np.array_equal(fm["order"], fc_by_n[n]["order"])))
+            m.close()
         # isPoseSafe: ONE pose (the pose of candidate 0 at its best yaw)
         pose = fs.synth.poses_from_yaw(w.goals[:1], np.array([float(rec_all["yaw"][0])]))
         for _ in range(20):
