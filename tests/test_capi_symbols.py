@@ -186,3 +186,27 @@ def test_build_stamps_go_by_content_never_by_mtime(tmp_path, monkeypatch):
     assert b.needs_build()
     b.build()
     assert len(compiled) == 3 and not b.needs_build()      # relinked from the current object, nothing recompiled
+
+
+def test_headers_are_plain_c_and_a_c_program_links_against_the_library(tmp_path, fs):
+    """The drop-in boundary is a C ABI: both headers compile as C99 (-pedantic, no C++ construct outside the extern "C" guards),
+    and a C program that names every declared entry point links against the built library (no GPU needed to link: nothing runs)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    names = _declared()
+    src = tmp_path / "abi.c"
+    body = "\n".join(f"    p[{i}] = (fn){n};" for i, n in enumerate(names))
+    src.write_text('#include <stddef.h>\n#include "fitslam_frontier.h"\n#include "fitslam_frontier_dev.h"\n'
+                   f"typedef void (*fn)(void);\nint main(void)\n{{\n    fn p[{len(names)}];\n    fs_record r; fs_ray_params rp; fs_fim_params fp; fs_frontier_cluster cl;\n"
+                   f"{body}\n    (void)r; (void)rp; (void)fp; (void)cl;\n    return p[0] && sizeof(fs_record) == 32 ? 0 : 1;\n}}\n")
+    inc = os.path.join(ROOT, "include")
+    res = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    lib = fs._build.LIB
+    exe = tmp_path / "abi"
+    res = subprocess.run([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, f"-Wl,-rpath,{os.path.dirname(lib)}",
+                          "-Wl,--unresolved-symbols=ignore-in-shared-libs"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
