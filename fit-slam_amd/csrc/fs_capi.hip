@@ -1556,6 +1556,29 @@ int fs_set_fim_params(fs_ctx *c, const fs_fim_params *p)
     return FS_OK;
 }
 
+// A call with few poses leaves most of the chip idle — ONE pose is one of 512 workgroup slots, and the reference's real call is one
+// pose per tick (FisherInfoBTPlugin.cpp:24-57): spread each pose over W = 2^shift workgroups by voxel slab (fs_fim.hip, SPLIT), as
+// long as all n * W items are resident at once and the cloud is big enough to be worth W workgroups' fixed cost (cull, table
+// clear, reduction): at least 128 chunks (8 k landmarks) per workgroup — C1's 2 k landmarks measured 3 us SLOWER split eight ways.
+// Same multiset of (voxel value, rank) terms; the partial sums are added in the finish kernel.  Sets a.split_shift / a.split_flags
+// and grows the per-item scratch; a.cone_mode / a.table_full / a.info_only must be filled in.
+static int maybe_split(fs_ctx *c, FsFimArgs &a, size_t n, bool want_fim21)
+{
+    a.split_shift = 0; a.split_flags = nullptr;
+    if (c->opt_split <= 0 || !fs_fim_can_split(a)) return FS_OK;
+    int shift = c->opt_split;
+    while (shift > 0 && ((n << shift) > 256 || (c->n_chunks >> shift) < 128)) --shift;
+    if (shift == 0) return FS_OK;
+    if (c->d_split_flags.cap < n) {
+        FS_HIP(c, c->d_split_flags.ensure(n));
+        FS_HIP(c, hipMemsetAsync(c->d_split_flags.p, 0, c->d_split_flags.cap * sizeof(uint32_t), c->stream));
+    }
+    const int rc = ensure_candidate_scratch(c, n << shift, want_fim21);
+    if (rc) return rc;
+    a.split_shift = shift; a.split_flags = c->d_split_flags.p;
+    return FS_OK;
+}
+
 static void bind_fim_outputs(fs_ctx *c, FsFimArgs &a)
 {
     a.info_ref = c->d_info.p; a.trace = c->d_trace.p; a.logdet = c->d_logdet.p;
@@ -1624,30 +1647,12 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
     // isPoseSafe reads the scalar alone (FIP/src/fisher_information/FisherInfoManager.cpp:83-100): a call that asks for nothing
     // but info_ref (and, at no cost, n_voxels) takes the worker without the 6x6 sums and with the exact table-box cull
     a.info_only = (c->opt_special && !fim21 && !trace && !logdet && !n_visible) ? 1 : 0;
-    // A call with few poses leaves most of the chip idle — ONE pose is one of 512 workgroup slots, and the reference's real call is
-    // one pose per tick (FisherInfoBTPlugin.cpp:24-57): spread each pose over W = 2^shift workgroups by voxel slab (fs_fim.hip, SPLIT),
-    // as long as all n * W items are resident at once.  Same multiset of (voxel value, rank) terms; the partial sums are added in the
-    // finish kernel.
-    a.split_shift = 0; a.split_flags = nullptr;
-    if (a.info_only && c->opt_split > 0 && fs_fim_can_split(a)) {
-        // ... and as long as the cloud is big enough to be worth W workgroups' fixed cost (cull, table clear, reduction): at least
-        // 128 chunks (8 k landmarks) per workgroup — C1's 2 k landmarks measured 3 us SLOWER split eight ways
-        int shift = c->opt_split;
-        while (shift > 0 && ((nn << shift) > 256 || (c->n_chunks >> shift) < 128)) --shift;
-        if (shift > 0) {
-            if (c->d_split_flags.cap < nn) {
-                FS_HIP(c, c->d_split_flags.ensure(nn));
-                FS_HIP(c, hipMemsetAsync(c->d_split_flags.p, 0, c->d_split_flags.cap * sizeof(uint32_t), c->stream));
-            }
-            rc = ensure_candidate_scratch(c, nn << shift, false);
-            if (rc) return rc;
-            a.split_shift = shift; a.split_flags = c->d_split_flags.p;
-        }
-    }
     // (the box cull leaves only chunks that can hold voxels of the table, so a pose shows more distinct voxels per landmark
     // scanned than the 13/32 the general worker caps its pass prediction at — C3, cone off: up to 0.5; an extra pass costs a
     // re-test of the landmarks, an overflow the HBM tier)
     if (a.info_only && a.skip32 < 20) a.skip32 = 20;
+    rc = maybe_split(c, a, nn, fim21 != nullptr);
+    if (rc) return rc;
     struct Col { void *host; const void *dev; size_t bytes; };
     const Col cols[6] = {{info_ref, c->d_info.p, 4 * nn}, {fim21, c->d_fim21.p, 84 * nn}, {trace, c->d_trace.p, 4 * nn},
                          {logdet, c->d_logdet.p, 4 * nn}, {n_visible, c->d_nvis.p, 4 * nn}, {n_voxels, c->d_nvox.p, 4 * nn}};
@@ -1883,13 +1888,15 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     if (ra.perm && c->opt_costmap) { fa.costmap = c->sort_costmap; fa.cand_key = c->sort_keys; }   // heavy blocks first next time
     fa.fim21 = nullptr;
     fa.yaw_only = (c->opt_special && c->yaw_exact) ? 1 : 0;   // the ray-march kernel copies the pose's rotation out of d_yawR
+    rc = maybe_split(c, fa, (size_t)n, false);                // a handful of frontiers: each pose over several workgroups
+    if (rc) return rc;
     bind_fim_outputs(c, fa);
     {
         ScopedTimer t(c, 0);
         FS_HIP(c, fs_launch_raymarch(ra, c->stream));
     }
     // the FIM kernel visits the candidates in the same spatial order: neighbouring poses walk the same landmark chunks
-    rc = run_fim_tier1(c, fa, ra.perm, 0, n);
+    rc = run_fim_tier1(c, fa, ra.perm, 0, n << fa.split_shift);
     if (rc) return rc;
     // the finish kernel assembles the records (one launch less than a separate pack)
     fa.records = d_records;

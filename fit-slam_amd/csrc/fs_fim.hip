@@ -357,10 +357,13 @@ enum { FS_CONE_OFF = 0, FS_CONE_NARROW = 1, FS_CONE_ANY = 2 };
 // scoring pass, but hashes only the landmarks whose voxel belongs to it — voxel_part over W x n_parts parts, the low bits of the
 // part id being w — so whole voxels stay in one workgroup (a voxel's ranks must be counted in one table), every landmark is scored
 // exactly once, and each workgroup needs 1/W of the table.  Partial sums go to slot pose * W + w; the finish kernel adds them.
+// The 6x6 block sums and the visible count follow the landmark: where they are taken at scoring time they are already partitioned
+// with the voxels; where they are taken at TEST time (cone off) the item that owns a landmark's slab takes them — every visible
+// landmark belongs to exactly one slab whether or not its voxel is in the table.
 template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY, bool SPLIT = false>
 __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits)
 {
-    static_assert(!SPLIT || (INFO_ONLY && !GLOBAL_TABLE), "the split worker exists for the info-only LDS tier");
+    static_assert(!SPLIT || (!GLOBAL_TABLE && TABLE_FULL && CONE != FS_CONE_ANY), "the split workers exist for the LDS tier, finite tables and the two common cone modes");
     const int split_shift = SPLIT ? a.split_shift : 0;
     const int split_w_mask = (1 << split_shift) - 1;
     constexpr uint32_t fail_code = GLOBAL_TABLE ? 3u : 2u;
@@ -721,7 +724,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     if (SUMS_AT_TEST) {
                         // the first pass of a candidate takes the sums and the count (later passes re-test the same landmarks)
                         if (part == 0) {
-                            const bool in_range = m3 >= 0.0f;
+                            bool in_range = m3 >= 0.0f;
+                            if (SPLIT) in_range = in_range && voxel_part(a, true, px, split_w_mask + 1) == split_w;   // (this item's slab: see SPLIT)
                             add_block_sums(acc, px, py, pz, (in_range && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f);
                             acc.nvis += in_range ? 1 : 0;
                         }
@@ -965,7 +969,23 @@ __device__ __forceinline__ void finish_body(const FsFimArgs &a, const int c)
         a.n_voxels[c] = (int)(nvox + 0.5);
         return;
     }
-    const double *S = a.sums + (size_t)c * FS_NACC;
+    // (one pose over W workgroups: the W partial sums of every quantity — unless the HBM tier redid the whole pose, whose result
+    // then stands alone in the pose's first slot)
+    double S[FS_NACC];
+    {
+        const double *S0 = a.sums + ((size_t)c << a.split_shift) * FS_NACC;
+#pragma unroll
+        for (int q = 0; q < FS_NACC; ++q) S[q] = S0[q];
+        if (a.split_shift > 0) {
+            const uint32_t flags = a.split_flags[c];
+            a.split_flags[c] = 0u;
+            if (!(flags & 2u))
+                for (int w = 1; w < (1 << a.split_shift); ++w) {
+#pragma unroll
+                    for (int q = 0; q < FS_NACC; ++q) S[q] += S0[(size_t)w * FS_NACC + q];
+                }
+        }
+    }
     const double *A = S + 1, *B = S + 7, *Sv = S + 13;
     // F = [[ B , -[s]x ], [ [s]x , A ]]   (block form of sum_k F(p_k))
     double F[6][6];
@@ -1132,11 +1152,11 @@ hipError_t launch_overflow(FsFimArgs &a, int pool, hipStream_t s)
 
 }  // namespace
 
-// one pose over several workgroups (FsFimArgs::split_shift) exists for the INFO_ONLY LDS worker only
+// one pose over several workgroups (FsFimArgs::split_shift) exists for finite tables and the two common cone modes
 bool fs_fim_can_split(const FsFimArgs &a)
 {
     const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
-    return a.table_full && cone != FS_CONE_ANY && a.info_only;
+    return a.table_full && cone != FS_CONE_ANY;
 }
 
 // which learnt voxel ratio a call works with (FsFimArgs::ratio_slot): 13 where the LDS worker that runs hashes from the chunks that
@@ -1161,6 +1181,11 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
     // shows more distinct voxels per landmark of THOSE than of everything in range: the cap of the pass prediction follows)
     if (cone == FS_CONE_OFF && a.skip32 < 20) a.skip32 = 20;
     const bool special = a.table_full && cone != FS_CONE_ANY;
+    if (a.split_shift > 0) {                                   // few poses: each over W workgroups (special holds: fs_fim_can_split)
+        if (a.info_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false, true>(a, s);
+        if (a.yaw_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, true, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, true, true>(a, s);
+        return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, false, true>(a, s);
+    }
     if (!special || (!a.info_only && !a.yaw_only)) {
         if (cone == FS_CONE_OFF) return a.table_full ? launch_tier1<true, FS_CONE_OFF, false, false>(a, s) : launch_tier1<false, FS_CONE_OFF, false, false>(a, s);
         if (cone == FS_CONE_NARROW) return a.table_full ? launch_tier1<true, FS_CONE_NARROW, false, false>(a, s) : launch_tier1<false, FS_CONE_NARROW, false, false>(a, s);
@@ -1168,8 +1193,6 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
     }
     // (info_only comes from fs_score_fim, whose poses are general; the fused path — the one with yaw-only poses — always wants
     // the full records: the two flags never meet, and no INFO_ONLY x YAW_ONLY worker is instantiated)
-    if (a.info_only && a.split_shift > 0)
-        return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false, true>(a, s);
     if (a.info_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false>(a, s);
     return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, true>(a, s);
 }

@@ -215,8 +215,43 @@ def test_one_pose_over_several_workgroups(fs, oracle, scorer, ref_table, angle):
                     got = scorer.score_fim(poses[:n], info_only=True)
                     np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"][:n], err_msg=f"split {split} n {n}")
                     assert np.max(np.abs(got["info_ref"] - want["info_f64"][:n]) / scale[:n]) <= REL, (split, n)
+                # every column (the general workers: sums at scoring time with the cone, at test time without it)
+                full = scorer.score_fim(poses[:n])
+                _check_fim(full, {k: v[:n] for k, v in want.items()}, w.landmarks.shape[0])
     finally:
         scorer.set_option("fim.split", 3)
+
+
+@pytest.mark.parametrize("name,angle", [("REF2D", 1.0), ("REF2D", 4.0), ("C2", 1.0), ("C2", 4.0)])
+def test_fused_scoring_of_a_few_frontiers_spreads_each_pose_over_workgroups(fs, oracle, scorer, ref_table, name, angle):
+    """fs_score_candidates with a handful of frontiers (the reference scores tens per tick) runs the YAW_ONLY workers with every
+    pose over several workgroups (REF2D's 1 563 chunks: eight; C2's 782: four): the records must be those of the unsplit call
+    (integers bit for bit) and the oracle's, whatever "fim.split" says."""
+    w = fs.synth.make_workload(name, n_cand=40)
+    G, P = _oracle_grid_params(oracle, w)
+    _setup_scorer(scorer, w)
+    scorer.set_fim_params(14.0, angle)
+    mx = oracle.max_arrival_information(G, P)
+    assert scorer.max_arrival() == mx
+    arr = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx["min_gt"], n_threads=8)
+    fim = oracle.pose_information(ref_table, w.landmarks, oracle.poses_from_yaw(w.goals, arr["yaw"]), 14.0, angle, n_threads=8)
+    try:
+        for split in (0, 3, 2):
+            scorer.set_option("fim.split", split)
+            for n in (1, 3, 17, 40):
+                rec = scorer.score_candidates(w.goals[:n], w.frontier_size[:n], w.blacklisted[:n])
+                ok = arr["status"][:n] == 0
+                np.testing.assert_array_equal(rec["arrival"], arr["arrival"][:n])
+                np.testing.assert_array_equal(rec["n_visible"][ok], fim["n_visible"][:n][ok], err_msg=f"split {split} n {n}")
+                np.testing.assert_array_equal(fs.capi.record_nvoxels(rec)[ok], np.minimum(fim["n_voxels"][:n][ok], 65535))
+                sc = np.maximum(np.abs(fim["info_f64"][:n][ok]), 1e-6)
+                assert np.max(np.abs(rec["info_ref"][ok] - fim["info_f64"][:n][ok]) / sc, initial=0.0) <= REL
+                assert np.max(np.abs(rec["trace"][ok] - fim["trace"][:n][ok]) / np.maximum(fim["trace"][:n][ok], 1e-6), initial=0.0) <= REL
+                gate = _parity().logdet_gate(rec["logdet"], fim["logdet"][:n], fim["fim"][:n], consider=ok, n_visible=fim["n_visible"][:n])
+                assert gate["ok"], (split, n, gate)
+    finally:
+        scorer.set_option("fim.split", 3)
+        scorer.set_fim_params(14.0, 1.0)
 
 
 def test_split_pose_that_overflows_goes_to_the_hbm_tier_whole(fs, oracle, scorer, ref_table):
@@ -250,9 +285,10 @@ def test_split_pose_that_overflows_goes_to_the_hbm_tier_whole(fs, oracle, scorer
                 got = scorer.score_fim(mixed, info_only=True)
                 np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
                 assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= REL
+            _check_fim(scorer.score_fim(mixed), want, lm.shape[0])       # every column through the same hand-over (general worker)
             if split == 1:
                 assert scorer.get_counter(5) >= hbm0 + 2                  # the HBM tier took the far poses (each ONCE per call)
-                assert scorer.get_counter(5) <= hbm0 + 4
+                assert scorer.get_counter(5) <= hbm0 + 6
     finally:
         scorer.set_option("fim.split", 3)
 
