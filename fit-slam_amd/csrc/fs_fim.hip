@@ -358,8 +358,8 @@ enum { FS_CONE_OFF = 0, FS_CONE_NARROW = 1, FS_CONE_ANY = 2 };
 // part id being w — so whole voxels stay in one workgroup (a voxel's ranks must be counted in one table), every landmark is scored
 // exactly once, and each workgroup needs 1/W of the table.  Partial sums go to slot pose * W + w; the finish kernel adds them.
 // The 6x6 block sums and the visible count follow the landmark: where they are taken at scoring time they are already partitioned
-// with the voxels; where they are taken at TEST time (cone off) the item that owns a landmark's slab takes them — every visible
-// landmark belongs to exactly one slab whether or not its voxel is in the table.
+// with the voxels; where they are taken at TEST time (cone off) the item that owns a landmark's CHUNK (chunk id mod W) takes them and
+// the other items skip that code — every visible landmark is in exactly one chunk.
 template <int THREADS, bool GLOBAL_TABLE, bool TABLE_FULL, int CONE, bool INFO_ONLY, bool YAW_ONLY, bool SPLIT = false>
 __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork work, uint32_t *lds, uint32_t *table, const int tier_bits)
 {
@@ -705,7 +705,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             uint32_t *scratch = reinterpret_cast<uint32_t *>(qz + 64);
             const uint32_t my_chunk = (uint32_t)(lane * WAVES + wave);
             // One chunk's landmarks in registers: test, compact, and score whenever 64 are queued.
-            auto body = [&](float wx, float wy, float wz) {
+            // (sums_here, wave-uniform: SUMS_AT_TEST under SPLIT — is this chunk one of those whose test-time sums this item takes?)
+            auto body = [&](float wx, float wy, float wz, const bool sums_here) {
                 // ---- 2. test: p = R^T (w - t), fp32 with the operation order fixed by DESIGN.md "FIM accumulate"
                 const float dx = wx - t[0], dy = wy - t[1], dz = wz - t[2];
                 const float px = YAW_ONLY ? __fmaf_rn(R[0], dx, R[3] * dy) : __fmaf_rn(R[0], dx, __fmaf_rn(R[3], dy, R[6] * dz));
@@ -723,9 +724,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     m3 = maxd2_v - n2;
                     if (SUMS_AT_TEST) {
                         // the first pass of a candidate takes the sums and the count (later passes re-test the same landmarks)
-                        if (part == 0) {
-                            bool in_range = m3 >= 0.0f;
-                            if (SPLIT) in_range = in_range && voxel_part(a, true, px, split_w_mask + 1) == split_w;   // (this item's slab: see SPLIT)
+                        if (part == 0 && (!SPLIT || sums_here)) {
+                            const bool in_range = m3 >= 0.0f;
                             add_block_sums(acc, px, py, pz, (in_range && n2 > 0.0f) ? __builtin_amdgcn_rcpf(n2) : 0.0f);
                             acc.nvis += in_range ? 1 : 0;
                         }
@@ -789,21 +789,26 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                 } while (g < a.n_groups);
                 if (n_ids == 0) break;                             // (only when every remaining mask was empty)
                 const uint32_t ids = scratch[lane];                // lanes >= n_ids: stale words, never drawn
-                auto fetch = [&](int j, float &x, float &y, float &z) {
+                auto fetch = [&](int j, float &x, float &y, float &z) -> int {
                     const int c = __builtin_amdgcn_readlane((int)ids, j);
                     const int cc = FS_BOUND(c >= 0 && c < a.n_chunks, 3) ? c : 0;
                     const uint32_t l = (uint32_t)(cc * 64 + lane);
                     x = ldg32(LX, l); y = ldg32(LY, l); z = ldg32(LZ, l);
+                    return cc;
                 };
                 // The next chunk's landmarks are in flight while the current one is tested; three cheap moves hand them over (one
                 // loop body, one inlined scoring call).  Past the end of the list the prefetch re-reads the last chunk (never used).
                 float nx_, ny_, nz_;
-                fetch(0, nx_, ny_, nz_);
+                int chunk_next = fetch(0, nx_, ny_, nz_);
                 const int last = n_ids - 1;
                 for (int j = 0; j <= last; ++j) {
                     const float wx = nx_, wy = ny_, wz = nz_;
-                    fetch(min(j + 1, last), nx_, ny_, nz_);
-                    body(wx, wy, wz);
+                    const int chunk_now = chunk_next;
+                    chunk_next = fetch(min(j + 1, last), nx_, ny_, nz_);
+                    // (SPLIT with the sums at test time: the CHUNK decides which of a pose's items takes a landmark's 6x6 sums and counts
+                    // it as visible — chunk id mod W, wave-uniform, so the other items skip that code altogether; the hash-table half
+                    // stays partitioned by voxel slab.  Every visible landmark is in exactly one chunk: counted exactly once.)
+                    body(wx, wy, wz, !SPLIT || !SUMS_AT_TEST || (chunk_now & split_w_mask) == split_w);
                 }
             }
         }

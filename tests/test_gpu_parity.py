@@ -177,17 +177,21 @@ def test_fim_learnt_pass_prediction_is_only_a_prediction(fs, oracle, scorer, ref
     far = np.zeros((2, 7)); far[:, 6] = 1.0; far[:, 0] = 200.0; far[1, 2] = 0.2
     scorer.upload_landmarks(lm)
     scorer.set_fim_params(14.0, 1.5)
-    hbm0 = scorer.get_counter(5)
-    got = scorer.score_fim(near)
-    _check_fim(got, oracle.pose_information(ref_table, lm, near, 14.0, 1.5, n_threads=8), lm.shape[0])
-    assert got["n_voxels"].max() * 20 < got["n_visible"].max()       # the clump is dense
-    assert scorer.get_counter(5) == hbm0                              # ... and fitted its tables
-    mixed = np.concatenate([near[:4], far])
-    want = oracle.pose_information(ref_table, lm, mixed, 14.0, 1.5, n_threads=8)
-    assert want["n_voxels"][4:].min() > 16384                         # more voxels than an LDS table has slots
-    for _ in range(2):                                                # the second time with the ratio the first one raised
-        _check_fim(scorer.score_fim(mixed), want, lm.shape[0])
-    assert scorer.get_counter(5) > hbm0
+    scorer.set_option("fim.split", 0)                                 # (one workgroup per pose: a split call neither learns nor needs to)
+    try:
+        hbm0 = scorer.get_counter(5)
+        got = scorer.score_fim(near)
+        _check_fim(got, oracle.pose_information(ref_table, lm, near, 14.0, 1.5, n_threads=8), lm.shape[0])
+        assert got["n_voxels"].max() * 20 < got["n_visible"].max()       # the clump is dense
+        assert scorer.get_counter(5) == hbm0                              # ... and fitted its tables
+        mixed = np.concatenate([near[:4], far])
+        want = oracle.pose_information(ref_table, lm, mixed, 14.0, 1.5, n_threads=8)
+        assert want["n_voxels"][4:].min() > 16384                         # more voxels than an LDS table has slots
+        for _ in range(2):                                                # the second time with the ratio the first one raised
+            _check_fim(scorer.score_fim(mixed), want, lm.shape[0])
+        assert scorer.get_counter(5) > hbm0
+    finally:
+        scorer.set_option("fim.split", 3)
 
 
 @pytest.mark.parametrize("angle", [1.0, 4.0])
