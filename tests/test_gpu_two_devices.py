@@ -3,8 +3,10 @@ first real evidence on the driver's multi-GPU node:
 
   * fs_multi_create({0, 1}): the records of a list scored half on each device equal a single context's (north_star's partition,
     the reference's in-process call shape: DEP/src/ExplorationBT.cpp:376-410);
-  * bench.py --gpus 2 --scaling strong through its own launcher: two ranks over RCCL, one all-gather per step, n_gpus == 2 in
-    the line, the gathered list gated against the oracle in every rank's block, both ranks named in the log.
+  * bench.py --gpus 2 through its own launcher (the driver's command shape): two ranks over RCCL, one all-gather per step,
+    n_gpus == 2 in the line, the weak value AND the strong-scaling block (160 k candidates split over the ranks), each gathered
+    list gated against the oracle in every rank's share, both ranks named in the log;
+  * fs_multi_get_frontier_costs on {0, 1}: member 1's block over the peer link (or the bounce) into the list on GPU 0.
 
 torch.cuda.device_count() does not initialise the GPU on this image, so collecting this module is harmless anywhere."""
 import json
@@ -100,14 +102,19 @@ def test_fs_multi_get_frontier_costs_gathers_over_the_peer_link(fs):
 def test_bench_two_ranks_over_rccl():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--steps", "3",
-                        "--warmup", "2", "--repeats", "3"], env=env, capture_output=True, text=True, timeout=900)
+    # the driver's own command shape: weak scaling as `value`, the strong-scaling block behind it in the same line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "2", "--repeats", "3", "--min-timed-seconds", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["value"] > 0
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["total_candidates"] == 40000
     assert j["parity"]["ok"], j["parity"]
+    st = j["strong_scaling"]
+    assert st["total_candidates"] == 160000 and st["candidate_goals_per_s"] > 0 and len(st["per_rank_ms_per_step"]) == 2
+    assert st["parity"]["ok"], st["parity"]
     assert "rank 0/2" in r.stderr and "rank 1/2" in r.stderr
     mg = j["multi_gpu"]
     assert len(mg["per_rank_ms_per_step"]) == 2 and mg["all_gather_ms"] > 0 and mg["barrier_skew_ms"] >= 0
