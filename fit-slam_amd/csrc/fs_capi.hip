@@ -1576,6 +1576,13 @@ static int maybe_split(fs_ctx *c, FsFimArgs &a, size_t n, bool want_fim21)
     const int rc = ensure_candidate_scratch(c, n << shift, want_fim21);
     if (rc) return rc;
     a.split_shift = shift; a.split_flags = c->d_split_flags.p;
+    // the stretch of the lattice along the camera's x axis that the W slabs divide evenly: where the table and the visibility range
+    // overlap (in front of the camera only when there is a cone) — the landmarks that get hashed.  Whatever lies outside goes to
+    // the open-ended first / last slab.
+    const int reach = (int)std::ceil(c->fp.max_dist * a.inv_step) + 1;
+    int lo = std::max(c->jx0, a.cone_mode == 1 ? 0 : -reach), hi = std::min(c->jx0 + c->tx - 1, reach);
+    if (hi < lo) hi = lo;
+    a.split_lo = lo; a.split_span = hi - lo + 1;
     return FS_OK;
 }
 

@@ -131,13 +131,18 @@ __device__ __forceinline__ uint32_t voxel_key(const FsFimArgs &a, bool active, f
 // Which of a candidate's n_parts (a power of two) scoring passes owns a landmark: the x index of its voxel, exactly as
 // voxel_key computes it, modulo n_parts — whole voxels go to one pass, neighbouring slabs of voxels alternate between
 // the passes (balanced), and only one coordinate has to be rounded.
-__device__ __forceinline__ int voxel_part(const FsFimArgs &a, bool active, float px, int n_parts)
+// the x index of a landmark's voxel (absolute lattice index, before the table's offset), exactly as voxel_key computes it
+__device__ __forceinline__ int voxel_jx(const FsFimArgs &a, bool active, float px)
 {
     const float rx = px * a.inv_step_f;
     const float nx = rintf(rx);
     int jx = (int)nx;
     if (active && (a.far_lattice || !(fabsf(rx - nx) < a.key_thr))) jx = (int)round((double)px * a.inv_step);
-    return (jx + 4096) & (n_parts - 1);
+    return jx;
+}
+__device__ __forceinline__ int voxel_part(const FsFimArgs &a, bool active, float px, int n_parts)
+{
+    return (voxel_jx(a, active, px) + 4096) & (n_parts - 1);
 }
 
 // Scores one queued landmark per lane (`active` false only for the empty lanes of the final partial batch): voxel key,
@@ -353,10 +358,10 @@ struct FimWork {
 // consumer sees) — the transform takes 7 instructions instead of 12.  The host checks the zeros before selecting it.
 enum { FS_CONE_OFF = 0, FS_CONE_NARROW = 1, FS_CONE_ANY = 2 };
 // SPLIT: ONE pose over W = 2^split_shift workgroups (the reference's real call is one pose per tick, FisherInfoBTPlugin.cpp:24-57 — one
-// of 512 workgroup slots).  A work item is then (pose, w): item id = pose * W + w.  Workgroup w tests every accepted chunk, like a
-// scoring pass, but hashes only the landmarks whose voxel belongs to it — voxel_part over W x n_parts parts, the low bits of the
-// part id being w — so whole voxels stay in one workgroup (a voxel's ranks must be counted in one table), every landmark is scored
-// exactly once, and each workgroup needs 1/W of the table.  Partial sums go to slot pose * W + w; the finish kernel adds them.
+// of 512 workgroup slots).  A work item is then (pose, w): item id = pose * W + w.  Workgroup w hashes only the landmarks whose
+// voxel lies in ITS slab of the lattice along the camera's x axis (slab_of) — whole voxels stay in one workgroup (a voxel's ranks
+// must be counted in one table), every landmark is scored exactly once, each workgroup needs 1/W of the table — and culls the chunk
+// list with that slab, so it tests only what can reach it.  Partial sums go to slot pose * W + w; the finish kernel adds them.
 // The 6x6 block sums and the visible count follow the landmark: where they are taken at scoring time they are already partitioned
 // with the voxels; where they are taken at TEST time (cone off) the item that owns a landmark's CHUNK (chunk id mod W) takes them and
 // the other items skip that code — every visible landmark is in exactly one chunk.
@@ -366,6 +371,14 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     static_assert(!SPLIT || (!GLOBAL_TABLE && TABLE_FULL && CONE != FS_CONE_ANY), "the split workers exist for the LDS tier, finite tables and the two common cone modes");
     const int split_shift = SPLIT ? a.split_shift : 0;
     const int split_w_mask = (1 << split_shift) - 1;
+    // item w of a split pose owns the voxels whose x index lies in [jlo, jhi): W contiguous slabs of the lattice along the camera's
+    // x axis (FsFimArgs::split_lo / split_span = the stretch worth balancing: where the table and the visibility range overlap), the
+    // first and the last one open-ended — every landmark, inside the table or not, belongs to exactly one item.  Contiguous, so an
+    // item CULLS with its own slab and tests only the chunks that can reach it: the test work is divided too, not only the hashing.
+    auto slab_of = [&](int w, int &jlo, int &jhi) {
+        jlo = w == 0 ? -(1 << 29) : a.split_lo + ((w * a.split_span) >> split_shift);
+        jhi = w == split_w_mask ? (1 << 29) : a.split_lo + (((w + 1) * a.split_span) >> split_shift);
+    };
     constexpr uint32_t fail_code = GLOBAL_TABLE ? 3u : 2u;
     // With the cone off, roughly half of what is visible (everything within range) lies outside the lookup table's box — behind the
     // camera, mostly — and only feeds the 6x6 sums and the visible count.  SUMS_AT_TEST adds those two for EVERY visible landmark
@@ -435,7 +448,16 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                         ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(spheres) + ((uint32_t)j << 4))
                         : make_float4(0.f, 0.f, 0.f, -1.0e30f);
     }
-    auto cull = [&](const PoseLoad &pl, int buf, float *Rn, float *tn) {
+    auto cull = [&](const PoseLoad &pl, int buf, float *Rn, float *tn, const int item_w) {
+        // (SPLIT: the faces of the item's slab in the camera frame, half a voxel beyond its outermost lattice planes plus a millimetre
+        // — the margin of the table's box below; open ends at +-1e30)
+        float slab_lo = -1.0e30f, slab_hi = 1.0e30f;
+        if (SPLIT) {
+            int jlo, jhi;
+            slab_of(item_w, jlo, jhi);
+            if (item_w != 0) slab_lo = (float)(((double)jlo - 0.5) / a.inv_step - 1.0e-3);
+            if (item_w != split_w_mask) slab_hi = (float)(((double)jhi - 0.5) / a.inv_step + 1.0e-3);
+        }
         unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
         unsigned long long *bmasks = masks + WAVES * a.n_groups;    // SUMS_AT_TEST: the accepted chunks that can meet the table's box
         const bool dead = (int)pose_word(pl, 12) != FS_STATUS_OK;
@@ -467,6 +489,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             const float bz = fminf((cz + s.w) - a.box_lo[2], a.box_hi[2] - (cz - s.w));
             return fminf(bx, fminf(by, bz));
         };
+        // ... and the same for the item's slab (SPLIT): >= 0 iff the sphere can hold a landmark whose voxel the item owns
+        auto slab_one = [&](const float4 s) -> float {
+            const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;
+            const float cx = dx * Rn[0] + dy * Rn[3] + (YAW_ONLY ? 0.0f : dz * Rn[6]);
+            return fminf((cx + s.w) - slab_lo, slab_hi - (cx - s.w));
+        };
         auto cull_one = [&](int j, const float4 s) -> float {
             if (!a.cull) return j < a.n_chunks ? 0.0f : -1.0f;        // brute force (wave-uniform)
             const float dx = s.x - t0, dy = s.y - t1, dz = s.z - t2;
@@ -474,6 +502,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             const float reach = a.max_dist_f + s.w, r2 = s.w * s.w;
             float c = fminf(reach, reach * reach - d2);               // within reach of the range sphere
             if (INFO_ONLY) c = fminf(c, box_one(s));
+            // (SPLIT: what is scored here is what the item owns.  The workers that take the 6x6 sums at test time keep the range mask
+            // whole for the chunks whose sums are theirs and apply the slab to the second mask: below)
+            if (SPLIT && !SUMS_AT_TEST) c = fminf(c, slab_one(s));
             if (CONE == FS_CONE_NARROW || (CONE == FS_CONE_ANY && a.cone_mode == 1)) {
                 // sphere vs cone of half-angle alpha < pi/2: angle(d, axis) <= alpha + asin(r/|d|), i.e.
                 // d.axis >= |d| cos(alpha + beta) = cos(alpha) sqrt(|d|^2 - r^2) - sin(alpha) r  (no division, one hardware
@@ -510,17 +541,21 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     const int j = (gb + u) * STRIDE + lane * WAVES + wave;
                     float c = cull_one(j, sp[u]);
                     asm volatile("" : "+v"(c));               // (keeps the compare out here, behind the merge of the two branches)
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(c >= 0.0f);
-                    tested += __popcll(mask);
-                    if (lane == 0) masks[gb + u] = mask;
+                    unsigned long long mask = __builtin_amdgcn_ballot_w64(c >= 0.0f);
                     if (SUMS_AT_TEST) {
                         // (a chunk outside the range sphere is outside both masks: the box value only matters where c >= 0)
                         float cb = a.cull ? box_one(sp[u]) : 0.0f;
+                        if (SPLIT && a.cull) cb = fminf(cb, slab_one(sp[u]));
                         asm volatile("" : "+v"(cb));
                         const unsigned long long bmask = __builtin_amdgcn_ballot_w64(cb >= 0.0f) & mask;
                         tested_box += __popcll(bmask);
                         if (lane == 0) bmasks[gb + u] = bmask;
+                        // (SPLIT: the first pass tests the chunks whose test-time sums are this item's — chunk id mod W — and those it can
+                        // hash from; nothing else in range concerns it)
+                        if (SPLIT) mask &= __builtin_amdgcn_ballot_w64(((uint32_t)j & (uint32_t)split_w_mask) == (uint32_t)item_w) | bmask;
                     }
+                    tested += __popcll(mask);
+                    if (lane == 0) masks[gb + u] = mask;
                 }
             }
         }
@@ -575,7 +610,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     if (cur >= 0) {
         if (GLOBAL_TABLE) first_pose = load_pose(cur >> split_shift);
         cur_key = pose_word(first_pose, 13);
-        cull(first_pose, 0, Rn, tn);
+        cull(first_pose, 0, Rn, tn, cur & split_w_mask);
     }
     __syncthreads();
 
@@ -586,6 +621,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     while (cur >= 0) {
         const int c = cur >> split_shift;                           // the pose; SPLIT: cur is the item id
         const int split_w = cur & split_w_mask;
+        int slab_jlo = 0, slab_jhi = 0;
+        if (SPLIT) slab_of(split_w, slab_jlo, slab_jhi);
 #ifdef FS_FIM_SCHEDULE
         // development build: when did this workgroup start the candidate and how long did it take (plain stores by one
         // thread, no atomics: the schedule of the persistent grid is read back through fs_get_counter)
@@ -623,7 +660,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (!GLOBAL_TABLE) {
             // = landmarks scanned * skip32 / 32, in 32 bits (beyond 2^20 accepted chunks the answer is the HBM tier anyway)
             const uint32_t scanned2 = (uint32_t)(wg_hash < (1 << 20) ? wg_hash : (1 << 20)) * 2u;
-            const uint32_t predicted = (scanned2 * (uint32_t)skip32_eff) >> split_shift;      // (SPLIT: this workgroup's 1/W of the voxels)
+            const uint32_t predicted = scanned2 * (uint32_t)skip32_eff;      // (SPLIT: wg_hash already counts the item's own chunks — those that reach its slab)
             const int k = (predicted > capacity ? 1 : 0) + (predicted > 2u * capacity ? 1 : 0) + (predicted > 4u * capacity ? 1 : 0) +
                           (predicted > 8u * capacity ? 1 : 0);
             n_parts = 1 << k;                                                         // 1, 2, 4, 8 passes
@@ -632,7 +669,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         int bits = tier_bits;
         if (!GLOBAL_TABLE && n_parts == 1) {
             // smallest table with at least as many slots as landmarks scanned, between 2^10 and the tier's size
-            const uint32_t want = ((uint32_t)wg_hash * 64u) >> split_shift;       // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
+            const uint32_t want = (uint32_t)wg_hash * 64u;       // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
             const int need = want > 1024u ? 32 - __builtin_clz(want - 1u) : 10;
             bits = need < tier_bits ? need : tier_bits;
         }
@@ -743,7 +780,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     else if (a.cone_mode == 2) v = v && ((px >= 0.0f) || (px2 <= a.cos2 * n2));
                     m3 = v ? 0.0f : -1.0f;
                 }
-                if (SPLIT) m3 = (voxel_part(a, true, px, n_parts << split_shift) == ((part << split_shift) | split_w)) ? m3 : -1.0f;
+                if (SPLIT) {
+                    // exact ownership: the voxel's x index inside the item's slab — and, when the item needs passes of its own, in this pass
+                    const int jx = voxel_jx(a, true, px);
+                    const bool mine = (uint32_t)(jx - slab_jlo) < (uint32_t)(slab_jhi - slab_jlo) && ((jx + 4096) & (n_parts - 1)) == part;
+                    m3 = mine ? m3 : -1.0f;
+                }
                 else if (__builtin_expect(n_parts > 1, 0)) m3 = (voxel_part(a, true, px, n_parts) == part) ? m3 : -1.0f;   // wave-uniform branch (out of line: a taken branch costs a wave its instruction buffer); every lane evaluates
                 const bool vis = m3 >= 0.0f;
                 // ---- 3. compact
@@ -832,7 +874,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         const bool draw = tid == 0 && nxt >= 0;
         unsigned long long ticket = 0ull;
         if (draw) ticket = atomicAdd(work.counter, 1ull);
-        if (nxt >= 0) cull(next_pose, buf ^ 1, Rn, tn);
+        if (nxt >= 0) cull(next_pose, buf ^ 1, Rn, tn, nxt & split_w_mask);
         if (nxt >= 0) next_key = pose_word(next_pose, 13);
         if (tid == 0) sh_next[buf] = draw ? item((int)ticket + preassigned) : -1;   // read by the next iteration after its first barrier
 

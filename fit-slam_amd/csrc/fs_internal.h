@@ -174,6 +174,7 @@ struct FsFimArgs {
     // tier's result stands in the pose's first slot).  0: off.
     int32_t split_shift;
     uint32_t *split_flags;
+    int32_t split_lo, split_span;   // the lattice x indices [split_lo, split_lo + split_span) the W slabs divide evenly (the first and last slab are open-ended)
     float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;
