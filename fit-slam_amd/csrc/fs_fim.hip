@@ -375,6 +375,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     // x axis (FsFimArgs::split_lo / split_span = the stretch worth balancing: where the table and the visibility range overlap), the
     // first and the last one open-ended — every landmark, inside the table or not, belongs to exactly one item.  Contiguous, so an
     // item CULLS with its own slab and tests only the chunks that can reach it: the test work is divided too, not only the hashing.
+    // (The workers that take the 6x6 sums at test time — cone off, full columns — keep INTERLEAVED slabs, x index mod W: they have
+    // to test every chunk in range for the sums anyway, and the even split of the hashing measured better there: 50 frontiers at the
+    // reference's request 105 against 120 us.)
     auto slab_of = [&](int w, int &jlo, int &jhi) {
         jlo = w == 0 ? -(1 << 29) : a.split_lo + ((w * a.split_span) >> split_shift);
         jhi = w == split_w_mask ? (1 << 29) : a.split_lo + (((w + 1) * a.split_span) >> split_shift);
@@ -545,13 +548,12 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     if (SUMS_AT_TEST) {
                         // (a chunk outside the range sphere is outside both masks: the box value only matters where c >= 0)
                         float cb = a.cull ? box_one(sp[u]) : 0.0f;
-                        if (SPLIT && a.cull) cb = fminf(cb, slab_one(sp[u]));
                         asm volatile("" : "+v"(cb));
                         const unsigned long long bmask = __builtin_amdgcn_ballot_w64(cb >= 0.0f) & mask;
                         tested_box += __popcll(bmask);
                         if (lane == 0) bmasks[gb + u] = bmask;
-                        // (SPLIT: the first pass tests the chunks whose test-time sums are this item's — chunk id mod W — and those it can
-                        // hash from; nothing else in range concerns it)
+                        // (SPLIT: the first pass tests the chunks whose test-time sums are this item's — chunk id mod W — and those anybody
+                        // can hash from; nothing else in range concerns it)
                         if (SPLIT) mask &= __builtin_amdgcn_ballot_w64(((uint32_t)j & (uint32_t)split_w_mask) == (uint32_t)item_w) | bmask;
                     }
                     tested += __popcll(mask);
@@ -660,7 +662,9 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (!GLOBAL_TABLE) {
             // = landmarks scanned * skip32 / 32, in 32 bits (beyond 2^20 accepted chunks the answer is the HBM tier anyway)
             const uint32_t scanned2 = (uint32_t)(wg_hash < (1 << 20) ? wg_hash : (1 << 20)) * 2u;
-            const uint32_t predicted = scanned2 * (uint32_t)skip32_eff;      // (SPLIT: wg_hash already counts the item's own chunks — those that reach its slab)
+            // (SPLIT: with contiguous slabs wg_hash already counts the item's own chunks — those that reach its slab; with interleaved
+            // slabs it counts every chunk anybody hashes from, of which the item owns 1/W of the voxels)
+            const uint32_t predicted = (scanned2 * (uint32_t)skip32_eff) >> (SUMS_AT_TEST ? split_shift : 0);
             const int k = (predicted > capacity ? 1 : 0) + (predicted > 2u * capacity ? 1 : 0) + (predicted > 4u * capacity ? 1 : 0) +
                           (predicted > 8u * capacity ? 1 : 0);
             n_parts = 1 << k;                                                         // 1, 2, 4, 8 passes
@@ -669,7 +673,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         int bits = tier_bits;
         if (!GLOBAL_TABLE && n_parts == 1) {
             // smallest table with at least as many slots as landmarks scanned, between 2^10 and the tier's size
-            const uint32_t want = (uint32_t)wg_hash * 64u;       // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
+            const uint32_t want = ((uint32_t)wg_hash * 64u) >> (SUMS_AT_TEST ? split_shift : 0);       // (3/4 of that measured 4 % slower: fuller buckets, more leftovers)
             const int need = want > 1024u ? 32 - __builtin_clz(want - 1u) : 10;
             bits = need < tier_bits ? need : tier_bits;
         }
@@ -780,7 +784,10 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
                     else if (a.cone_mode == 2) v = v && ((px >= 0.0f) || (px2 <= a.cos2 * n2));
                     m3 = v ? 0.0f : -1.0f;
                 }
-                if (SPLIT) {
+                if (SPLIT && SUMS_AT_TEST) {
+                    // (interleaved slabs: part id = pass << shift | w)
+                    m3 = (voxel_part(a, true, px, n_parts << split_shift) == ((part << split_shift) | split_w)) ? m3 : -1.0f;
+                } else if (SPLIT) {
                     // exact ownership: the voxel's x index inside the item's slab — and, when the item needs passes of its own, in this pass
                     const int jx = voxel_jx(a, true, px);
                     const bool mine = (uint32_t)(jx - slab_jlo) < (uint32_t)(slab_jhi - slab_jlo) && ((jx + 4096) & (n_parts - 1)) == part;
