@@ -1576,13 +1576,34 @@ static int maybe_split(fs_ctx *c, FsFimArgs &a, size_t n, bool want_fim21)
     const int rc = ensure_candidate_scratch(c, n << shift, want_fim21);
     if (rc) return rc;
     a.split_shift = shift; a.split_flags = c->d_split_flags.p;
-    // the stretch of the lattice along the camera's x axis that the W slabs divide evenly: where the table and the visibility range
-    // overlap (in front of the camera only when there is a cone) — the landmarks that get hashed.  Whatever lies outside goes to
-    // the open-ended first / last slab.
-    const int reach = (int)std::ceil(c->fp.max_dist * a.inv_step) + 1;
-    int lo = std::max(c->jx0, a.cone_mode == 1 ? 0 : -reach), hi = std::min(c->jx0 + c->tx - 1, reach);
-    if (hi < lo) hi = lo;
-    a.split_lo = lo; a.split_span = hi - lo + 1;
+    // The W contiguous slabs of the lattice along the camera's x axis (fs_fim.hip, slab_of): cut so that every slab holds the same
+    // share of the visibility volume's cross-section over the stretch where the table and the range overlap (in front of the
+    // camera only when there is a cone) — plane j at x = j * step shows a disc of radius^2 = min(max_dist^2 - x^2, (x tan(angle))^2).
+    // Uniform landmark density assumed; what lies outside the stretch goes to the open-ended first / last slab.
+    {
+        const int W = 1 << shift;
+        const double step = 1.0 / a.inv_step, R = c->fp.max_dist;
+        const int reach = (int)std::ceil(R * a.inv_step) + 1;
+        const bool cone = a.cone_mode == 1;
+        int lo = std::max(c->jx0, cone ? 0 : -reach), hi = std::min(c->jx0 + c->tx - 1, reach);
+        if (hi < lo) hi = lo;
+        const double tan2 = cone ? std::pow(std::tan(std::min(c->fp.max_angle, 1.55)), 2) : 0.0;
+        std::vector<double> cum((size_t)(hi - lo + 2), 0.0);
+        for (int j = lo; j <= hi; ++j) {
+            const double x = j * step;
+            double r2 = std::max(R * R - x * x, 0.0);
+            if (cone) r2 = std::min(r2, x * x * tan2);
+            cum[(size_t)(j - lo + 1)] = cum[(size_t)(j - lo)] + r2 + 1e-9;      // (+ eps: strictly increasing, so every slab gets planes while there are any)
+        }
+        a.split_bound[0] = -(1 << 29);
+        a.split_bound[W] = 1 << 29;
+        int j = lo;
+        for (int w = 1; w < W; ++w) {
+            const double want = cum.back() * (double)w / (double)W;
+            while (j < hi && cum[(size_t)(j - lo + 1)] < want) ++j;
+            a.split_bound[w] = std::max(j, a.split_bound[w - 1] > -(1 << 28) ? a.split_bound[w - 1] : lo);
+        }
+    }
     return FS_OK;
 }
 

@@ -372,15 +372,20 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
     const int split_shift = SPLIT ? a.split_shift : 0;
     const int split_w_mask = (1 << split_shift) - 1;
     // item w of a split pose owns the voxels whose x index lies in [jlo, jhi): W contiguous slabs of the lattice along the camera's
-    // x axis (FsFimArgs::split_lo / split_span = the stretch worth balancing: where the table and the visibility range overlap), the
+    // x axis (FsFimArgs::split_bound, cut by the host into equal shares of the visibility volume inside the table), the
     // first and the last one open-ended — every landmark, inside the table or not, belongs to exactly one item.  Contiguous, so an
     // item CULLS with its own slab and tests only the chunks that can reach it: the test work is divided too, not only the hashing.
     // (The workers that take the 6x6 sums at test time — cone off, full columns — keep INTERLEAVED slabs, x index mod W: they have
     // to test every chunk in range for the sums anyway, and the even split of the hashing measured better there: 50 frontiers at the
     // reference's request 105 against 120 us.)
     auto slab_of = [&](int w, int &jlo, int &jhi) {
-        jlo = w == 0 ? -(1 << 29) : a.split_lo + ((w * a.split_span) >> split_shift);
-        jhi = w == split_w_mask ? (1 << 29) : a.split_lo + (((w + 1) * a.split_span) >> split_shift);
+        // (constant indices: a dynamically indexed kernel argument would be copied to scratch; a chain of scalar selects, once per item)
+        jlo = a.split_bound[0]; jhi = a.split_bound[1];
+#pragma unroll
+        for (int k = 1; k < 32; ++k) {
+            jlo = (k == w) ? a.split_bound[k] : jlo;
+            jhi = (k == w) ? a.split_bound[k + 1] : jhi;
+        }
     };
     constexpr uint32_t fail_code = GLOBAL_TABLE ? 3u : 2u;
     // With the cone off, roughly half of what is visible (everything within range) lies outside the lookup table's box — behind the
@@ -458,8 +463,8 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
         if (SPLIT) {
             int jlo, jhi;
             slab_of(item_w, jlo, jhi);
-            if (item_w != 0) slab_lo = (float)(((double)jlo - 0.5) / a.inv_step - 1.0e-3);
-            if (item_w != split_w_mask) slab_hi = (float)(((double)jhi - 0.5) / a.inv_step + 1.0e-3);
+            if (jlo > -(1 << 28)) slab_lo = (float)(((double)jlo - 0.5) / a.inv_step - 1.0e-3);
+            if (jhi < (1 << 28)) slab_hi = (float)(((double)jhi - 0.5) / a.inv_step + 1.0e-3);
         }
         unsigned long long *masks = Lds<THREADS>::masks(lds, a.n_groups) + wave * a.n_groups;
         unsigned long long *bmasks = masks + WAVES * a.n_groups;    // SUMS_AT_TEST: the accepted chunks that can meet the table's box

@@ -174,7 +174,10 @@ struct FsFimArgs {
     // tier's result stands in the pose's first slot).  0: off.
     int32_t split_shift;
     uint32_t *split_flags;
-    int32_t split_lo, split_span;   // the lattice x indices [split_lo, split_lo + split_span) the W slabs divide evenly (the first and last slab are open-ended)
+    // slab w of a split pose = lattice x indices [split_bound[w], split_bound[w + 1]) (contiguous slabs; the first and the last one
+    // are open-ended): cut by the host so that every slab holds the same share of the visibility volume's cross-section inside
+    // the table (FS_SPLIT_MAX_W slabs at most)
+    int32_t split_bound[33];
     float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;
