@@ -51,7 +51,7 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * "fim.split" (default 3): a call with so few poses that the chip would idle — fs_score_fim with one or a few poses, fs_score_candidates
  * with a handful of frontiers — spreads each pose over up to 2^value workgroups by voxel slab (all n * W items resident, >= 128
  * landmark chunks per workgroup); 0 = one workgroup per pose.  Identical integers, the same multiset of information terms.  (One
- * isPoseSafe pose at the reference's visibility request: 60 -> 46 us; 50 frontiers through the fused path: 123 -> 105 us.)
+ * isPoseSafe pose at the reference's visibility request: 60 -> 42 us; 50 frontiers through the fused path: 122 -> 104 us.)
  * "fim.specialise" (default 1): 0 = always the general FIM worker (no INFO_ONLY / YAW_ONLY instantiation; identical integers,
  * float sums to the last bits) — the A/B switch of tests/test_gpu_reference_visibility.py. */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);
