@@ -203,6 +203,15 @@ struct fs_ctx {
     struct PendingCol { void *host; size_t off, bytes; };
     std::vector<PendingCol> arrival_pending;
     std::vector<PendingCol> fim_pending;           // fs_score_fim_begin -> _end, likewise
+    // ... and the finish of a split info-only call that fs_score_fim_end runs on the HOST (host_finish, fs_score_fim_begin): the
+    // partial sums of every (pose, w) item land in mapped page-locked memory behind a flag word; the kernel arguments are kept for
+    // the rare call that needs the HBM tier and the finish kernel after all
+    PinnedBuf h_fin;
+    bool fin_active = false;
+    FsFimArgs fin_args{};
+    size_t fin_off_info = 0, fin_off_nvox = 0;
+    bool fin_want_nvox = false;
+    bool opt_host_finish = true;   // "fim.hostfinish"
     // the gather role of fs_multi_get_frontier_costs' member 0 (its own block still goes through h_in / d_in): the planner's
     // path columns and the blacklist of the WHOLE list; the gathered records live in d_out, ahead of the ranking's columns
     PinnedBuf h_gin;
@@ -793,7 +802,7 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_overflow.release(); c->d_tested.release(); c->d_split_flags.release(); c->d_flagged.release(); c->d_records.release();
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->sort_scratch) (void)hipFree(c->sort_scratch);
-    c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release();
+    c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release(); c->h_fin.release();
     c->d_seg_start.release(); c->d_seg_end.release(); c->d_tri.release(); c->d_seg_ok.release(); c->d_seg_hit.release();
     c->d_mask.release(); c->d_brick_cells.release(); c->d_seg_traced.release(); c->d_seg_unknown.release();
     c->d_seg_all.release(); c->d_brick_xyz.release(); c->d_bad.release(); c->d_count.release();
@@ -1446,6 +1455,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "fim.hostfinish") == 0) { c->opt_host_finish = value != 0; ++c->epoch; return FS_OK; }
     if (std::strcmp(key, "fim.split") == 0 && value >= 0 && value <= 5) { c->opt_split = (int)value; ++c->epoch; return FS_OK; }
     if (std::strcmp(key, "ray.layout") == 0 && value >= 0 && value <= 3) { c->opt_layout = (int)value; return FS_OK; }
     if (std::strcmp(key, "fim.bits1") == 0 && value >= 10 && value <= 14) { c->opt_bits1 = (int)value; return FS_OK; }
@@ -1691,6 +1701,20 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
     // up to FS_ZERO_COPY_MAX_N poses the worker reads the pose records from, and the finish kernel writes the requested columns
     // into, the mapped page-locked buffers: the call is three launches and one synchronisation, no transfers
     const bool in_place = c->opt_zero_copy && n <= FS_ZERO_COPY_MAX_N && c->h_in.dev && c->h_out.dev;
+    // ONE launch for the isPoseSafe call.  A split info-only call needs the finish kernel only to add W partial sums per pose, and the
+    // HBM-tier launch only if an item ran out of table: both are launches of ~4.6 us of GPU timeline each.  Here the items write
+    // their partial sums into mapped page-locked memory, fs_score_fim_end adds them on the host (the same double additions in the
+    // same order as the finish kernel: same bits) — and only if an item raised the flag next to them does it launch the HBM tier
+    // and the finish kernel after all and wait a second time.  (What the finish kernel also does per call — folding the test
+    // counts into the running totals, zeroing per-call counters — is deferred to the next call that runs it: statistics only; the
+    // work cursor is untouched by a call whose items all fit the grid, which split calls do by construction.)
+    const bool host_finish = c->opt_host_finish && a.info_only && a.split_shift > 0 && in_place && !c->timing && !c->opt_graph;
+    c->fin_active = false;
+    if (host_finish) {
+        FS_HIP(c, c->h_fin.ensure(16 + sizeof(double) * 18 * (nn << a.split_shift)));
+        if (!c->h_fin.dev) return fail(c, FS_E_HIP, "mapped page-locked memory unavailable");
+        std::memset(c->h_fin.p, 0, 16);
+    }
     auto enqueue = [&]() -> int {
         if (in_place) a.Rt = reinterpret_cast<const float *>(c->h_in.dev);
         else FS_HIP(c, hipMemcpyAsync(c->d_Rt.p, c->h_in.p, nn * 12 * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -1705,8 +1729,13 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
                 o += (cols[k].bytes + 15) & ~(size_t)15;
             }
         }
+        if (host_finish) {
+            a.sums = reinterpret_cast<double *>(c->h_fin.dev + 16);
+            a.host_flag = reinterpret_cast<uint32_t *>(c->h_fin.dev);
+        }
         int r = run_fim_tier1(c, a, nullptr, 0, a.n << a.split_shift);      // (split: n * W work items)
         if (r) return r;
+        if (host_finish) { c->fin_args = a; c->fin_active = true; return FS_OK; }
         r = run_fim_rest(c, a);
         if (r) return r;
         if (in_place) return FS_OK;
@@ -1723,11 +1752,15 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
     else rc = enqueue();
     if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     size_t off = 0;
-    for (const Col &col : cols) {
+    for (int k = 0; k < 6; ++k) {
+        const Col &col = cols[k];
         if (!col.host) continue;
+        if (k == 0) c->fin_off_info = off;
+        if (k == 5) c->fin_off_nvox = off;
         c->fim_pending.push_back({col.host, off, col.bytes});
         off += (col.bytes + 15) & ~(size_t)15;
     }
+    c->fin_want_nvox = n_voxels != nullptr;
     return FS_OK;
 }
 
@@ -1737,7 +1770,32 @@ int fs_score_fim_end(fs_ctx *c)
     if (c->fim_pending.empty()) return FS_OK;
     FS_HIP(c, hipSetDevice(c->device));
     const hipError_t e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { c->fim_pending.clear(); return fail(c, FS_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { c->fim_pending.clear(); c->fin_active = false; return fail(c, FS_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
+    if (c->fin_active) {
+        c->fin_active = false;
+        const FsFimArgs &a = c->fin_args;
+        uint32_t flag = 0;
+        std::memcpy(&flag, c->h_fin.p, 4);
+        if (flag == 0) {
+            // the finish kernel's info-only branch (fs_fim.hip), on the host: W partial sums per pose, added in item order
+            const double *S = reinterpret_cast<const double *>(c->h_fin.p + 16);
+            float *info = reinterpret_cast<float *>(c->h_out.p + c->fin_off_info);
+            int32_t *nvox = c->fin_want_nvox ? reinterpret_cast<int32_t *>(c->h_out.p + c->fin_off_nvox) : nullptr;
+            const int W = 1 << a.split_shift;
+            for (int32_t p = 0; p < a.n; ++p) {
+                const double *S0 = S + ((size_t)p << a.split_shift) * 18;
+                double s_info = S0[0], s_nvox = S0[17];
+                for (int w = 1; w < W; ++w) { s_info += S0[(size_t)w * 18]; s_nvox += S0[(size_t)w * 18 + 17]; }
+                info[p] = (float)s_info;
+                if (nvox) nvox[p] = (int)(s_nvox + 0.5);
+            }
+        } else {
+            // an item ran out of table: the HBM tier redoes the flagged poses, the finish kernel sorts out which result stands
+            const int rc = run_fim_rest(c, c->fin_args);
+            const hipError_t e2 = hipStreamSynchronize(c->stream);
+            if (rc || e2 != hipSuccess) { c->fim_pending.clear(); return rc ? rc : fail(c, FS_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e2)); }
+        }
+    }
     for (const fs_ctx::PendingCol &col : c->fim_pending) std::memcpy(col.host, c->h_out.p + col.off, col.bytes);
     c->fim_pending.clear();
     return FS_OK;

@@ -948,6 +948,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             // (SPLIT: the first of a pose's items to fail hands the WHOLE pose over, once; the HBM tier's result then replaces the
             // partial sums — flag 2 tells the finish kernel to read the pose's first slot alone)
             const bool hand_over = failed && !GLOBAL_TABLE && (!SPLIT || (atomicOr(&a.split_flags[c], 1u) & 1u) == 0u);
+            if (SPLIT && failed && a.host_flag) __hip_atomic_store(a.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host then runs the HBM tier and the finish kernel after all)
             if (hand_over) {
                 const unsigned long long slot = atomicAdd(&a.counters[2], 1ull);
                 if (FS_BOUND(slot < (unsigned long long)a.n, 4)) a.flagged[slot] = c;          // work list of the HBM tier

@@ -178,6 +178,9 @@ struct FsFimArgs {
     // are open-ended): cut by the host so that every slab holds the same share of the visibility volume's cross-section inside
     // the table (FS_SPLIT_MAX_W slabs at most)
     int32_t split_bound[33];
+    // a split info-only call whose finish runs on the HOST (fs_capi.hip, host_finish): `sums` then points into mapped page-locked
+    // memory, and an item that hands its pose to the HBM tier also raises this word there (plain store; nullptr: not such a call)
+    uint32_t *host_flag;
     float box_lo[3], box_hi[3];       // the lookup table's box in the camera frame: half a voxel beyond the outermost lattice points, plus 1 mm
     // poses: Rt[n][12] (R row-major 9 + t 3), written by the host (explicit poses) or by the ray-march kernel
     int32_t n;

@@ -52,6 +52,9 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * with a handful of frontiers — spreads each pose over up to 2^value workgroups by voxel slab (all n * W items resident, >= 128
  * landmark chunks per workgroup); 0 = one workgroup per pose.  Identical integers, the same multiset of information terms.  (One
  * isPoseSafe pose at the reference's visibility request: 60 -> 42 us; 50 frontiers through the fused path: 122 -> 104 us.)
+ * "fim.hostfinish" (default 1): a split info-only call (the isPoseSafe call) is ONE launch — its items write their partial sums
+ * into mapped page-locked memory and the host adds them after the synchronisation (same additions, same order as the finish
+ * kernel); the HBM-tier and finish launches follow only if an item ran out of table.  0 = always three launches.
  * "fim.specialise" (default 1): 0 = always the general FIM worker (no INFO_ONLY / YAW_ONLY instantiation; identical integers,
  * float sums to the last bits) — the A/B switch of tests/test_gpu_reference_visibility.py. */
 int  fs_set_option(fs_ctx *ctx, const char *key, double value);

@@ -222,8 +222,17 @@ def test_one_pose_over_several_workgroups(fs, oracle, scorer, ref_table, angle):
                 # every column (the general workers: sums at scoring time with the cone, at test time without it)
                 full = scorer.score_fim(poses[:n])
                 _check_fim(full, {k: v[:n] for k, v in want.items()}, w.landmarks.shape[0])
+                # the info-only call adds its W partial sums on the HOST (one launch); with the finish kernel instead the same
+                # doubles are added in the same order (the terms INSIDE a partial sum may differ by the order of racing LDS atomics
+                # from call to call: a few ulp between two calls, not bit equality)
+                scorer.set_option("fim.hostfinish", 0)
+                dev = scorer.score_fim(poses[:n], info_only=True)
+                scorer.set_option("fim.hostfinish", 1)
+                np.testing.assert_array_equal(dev["n_voxels"], got["n_voxels"])
+                assert np.max(np.abs(dev["info_ref"].astype(np.float64) - got["info_ref"]) / np.maximum(np.abs(got["info_ref"]), 1.0)) <= 2e-6
     finally:
         scorer.set_option("fim.split", 3)
+        scorer.set_option("fim.hostfinish", 1)
 
 
 @pytest.mark.parametrize("name,angle", [("REF2D", 1.0), ("REF2D", 4.0), ("C2", 1.0), ("C2", 4.0)])
