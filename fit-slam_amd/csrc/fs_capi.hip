@@ -1578,7 +1578,9 @@ static int maybe_split(fs_ctx *c, FsFimArgs &a, size_t n, bool want_fim21)
     if (c->opt_split <= 0 || !fs_fim_can_split(a)) return FS_OK;
     int shift = c->opt_split;
     while (shift > 0 && ((n << shift) > 256 || (c->n_chunks >> shift) < 128)) --shift;
-    if (shift == 0) return FS_OK;
+    // (W = 1 — a cloud too small to be worth several workgroups — still goes through the split workers when the call asks for
+    // info_ref alone and has few poses: they are what lets fs_score_fim_end do the finish on the host, one launch instead of three)
+    if (shift == 0 && !(a.info_only && c->opt_host_finish && n <= 256)) return FS_OK;
     if (c->d_split_flags.cap < n) {
         FS_HIP(c, c->d_split_flags.ensure(n));
         FS_HIP(c, hipMemsetAsync(c->d_split_flags.p, 0, c->d_split_flags.cap * sizeof(uint32_t), c->stream));
@@ -1708,7 +1710,7 @@ int fs_score_fim_begin(fs_ctx *c, int32_t n, const double *pose7, float *info_re
     // and the finish kernel after all and wait a second time.  (What the finish kernel also does per call — folding the test
     // counts into the running totals, zeroing per-call counters — is deferred to the next call that runs it: statistics only; the
     // work cursor is untouched by a call whose items all fit the grid, which split calls do by construction.)
-    const bool host_finish = c->opt_host_finish && a.info_only && a.split_shift > 0 && in_place && !c->timing && !c->opt_graph;
+    const bool host_finish = c->opt_host_finish && a.info_only && a.split_flags && in_place && !c->timing && !c->opt_graph;
     c->fin_active = false;
     if (host_finish) {
         FS_HIP(c, c->h_fin.ensure(16 + sizeof(double) * 18 * (nn << a.split_shift)));

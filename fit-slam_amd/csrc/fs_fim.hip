@@ -955,7 +955,7 @@ __device__ __forceinline__ void fim_worker(const FsFimArgs &a, const FimWork wor
             } else if (failed && GLOBAL_TABLE) {
                 atomicAdd(&a.counters[3], 1ull);
             }
-            if (GLOBAL_TABLE && a.split_shift > 0 && !failed) atomicOr(&a.split_flags[c], 2u);
+            if (GLOBAL_TABLE && a.split_flags && !failed) atomicOr(&a.split_flags[c], 2u);
         }
         cur = nxt;
         cur_key = next_key;
@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void finish_body(const FsFimArgs &a, const int c)
     if (a.info_only) {                                       // isPoseSafe's scalar and the voxel count: nothing else was accumulated
         const double *S1 = a.sums + ((size_t)c << a.split_shift) * FS_NACC;
         double info = S1[0], nvox = S1[17];
-        if (a.split_shift > 0) {
+        if (a.split_flags) {
             // one pose over W workgroups: the W partial sums — unless the HBM tier redid the whole pose (flag 2: first slot alone)
             const uint32_t flags = a.split_flags[c];
             a.split_flags[c] = 0u;                           // (left clean for the next call)
@@ -1036,7 +1036,7 @@ __device__ __forceinline__ void finish_body(const FsFimArgs &a, const int c)
         const double *S0 = a.sums + ((size_t)c << a.split_shift) * FS_NACC;
 #pragma unroll
         for (int q = 0; q < FS_NACC; ++q) S[q] = S0[q];
-        if (a.split_shift > 0) {
+        if (a.split_flags) {
             const uint32_t flags = a.split_flags[c];
             a.split_flags[c] = 0u;
             if (!(flags & 2u))
@@ -1234,14 +1234,14 @@ hipError_t fs_launch_fim(const FsFimArgs &a0, hipStream_t s)
     FsFimArgs a = a0;
     a.ratio_slot = ratio_slot_of(a);
     const int cone = a.cone_mode == 0 ? FS_CONE_OFF : (a.cone_mode == 1 ? FS_CONE_NARROW : FS_CONE_ANY);
-    if (a.split_shift > 0 && !fs_fim_can_split(a)) return hipErrorInvalidValue;   // (the host asks fs_fim_can_split before it sets the shift)
+    if (a.split_flags && !fs_fim_can_split(a)) return hipErrorInvalidValue;   // (the host asks fs_fim_can_split before it sets up a split call)
     // The specialised workers exist for finite tables (every generated one) and the two common cone modes; anything else runs the
     // general worker, which computes a superset (the finish kernel then hands out what was asked for).
     // (the cone-off workers size their passes by the chunks that can meet the table's box — SUMS_AT_TEST, INFO_ONLY —, and a pose
     // shows more distinct voxels per landmark of THOSE than of everything in range: the cap of the pass prediction follows)
     if (cone == FS_CONE_OFF && a.skip32 < 20) a.skip32 = 20;
     const bool special = a.table_full && cone != FS_CONE_ANY;
-    if (a.split_shift > 0) {                                   // few poses: each over W workgroups (special holds: fs_fim_can_split)
+    if (a.split_flags) {                                       // few poses: each over W workgroups — W = 1 included (special holds: fs_fim_can_split)
         if (a.info_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, true, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, true, false, true>(a, s);
         if (a.yaw_only) return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, true, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, true, true>(a, s);
         return cone == FS_CONE_OFF ? launch_tier1<true, FS_CONE_OFF, false, false, true>(a, s) : launch_tier1<true, FS_CONE_NARROW, false, false, true>(a, s);
