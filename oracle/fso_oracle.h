@@ -10,9 +10,12 @@
  *   DEP/ = dev_ws/src/DEPRECATED/frontier_exploration/frontier_exploration/
  *   FIP/ = dev_ws/src/fit-slam2/fisher_information_plugins/
  *
- * PARITY PIN STATUS: the reference has no automated tests, no golden
- * vectors and no fixtures for this path, and it cannot be compiled here (ROS 2 Humble,
- * Eigen3, nav2, BT.CPP, two un-vendored submodules).  The oracle is therefore pinned
+ * PARITY PIN STATUS: PARITY UNPINNED in the strict sense — the reference
+ * has no automated tests, no golden vectors and no fixtures with expected values for this
+ * path, and it cannot be compiled here (ROS 2 Humble, Eigen3, nav2, BT.CPP, two un-vendored
+ * submodules), so no output of the reference itself is available to check against.  What
+ * it does hold — the INPUTS of its three manual programs — is committed
+ * (tests/golden/ref_held_inputs.npz) and replayed.  Short of that the oracle is pinned
  * by (i) the analytic known answers derivable from the reference's own manual test
  * inputs (DEP/tests/main_fim_computation.cpp:8-56, DEP/tests/fim_viz.cpp:70-100),
  * (ii) an independent slow Python transcription (oracle/pyref.py) and (iii) property
