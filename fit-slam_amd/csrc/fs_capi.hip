@@ -1626,6 +1626,7 @@ static void bind_fim_outputs(fs_ctx *c, FsFimArgs &a)
     a.sums = c->d_sums.p;
     a.tested = c->d_tested.p;
     a.flagged = c->d_flagged.p;
+    if (a.fim21) a.fim21 = c->d_fim21.p;       // (maybe_split may have grown — moved — the column since the caller asked for it)
 }
 
 // tier 1 on candidates [lo, lo + count) of the processing order
@@ -1958,6 +1959,15 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     if (n == 0) return FS_OK;
     rc = ensure_candidate_scratch(c, n, false);
     if (rc) return rc;
+    // What decides the size of the per-item scratch comes FIRST: a short list spreads each pose over several workgroups
+    // (maybe_split), which may grow — and so move — every per-candidate column; no pointer into them is taken before that.
+    FsFimArgs fa{};
+    fill_fim_args(c, fa);
+    fa.n = n;
+    fa.fim21 = nullptr;
+    fa.yaw_only = (c->opt_special && c->yaw_exact) ? 1 : 0;   // the ray-march kernel copies the pose's rotation out of d_yawR
+    rc = maybe_split(c, fa, (size_t)n, false);                // a handful of frontiers: each pose over several workgroups
+    if (rc) return rc;
     FsRayArgs ra{};
     if (const int rc_args = fill_ray_args(c, ra)) return rc_args;
     ra.n = n; ra.goal = d_goal_xyz;
@@ -1969,15 +1979,9 @@ int fs_score_candidates_dev(fs_ctx *c, int32_t n, const double *d_goal_xyz, cons
     ra.yawR = c->d_yawR.p; ra.pose12 = c->d_Rt.p;
     rc = maybe_sort(c, ra);
     if (rc) return rc;
-    FsFimArgs fa{};
-    fill_fim_args(c, fa);
-    fa.n = n; fa.Rt = c->d_Rt.p;
+    fa.Rt = c->d_Rt.p;
     fa.status = c->d_status.p;
     if (ra.perm && c->opt_costmap) { fa.costmap = c->sort_costmap; fa.cand_key = c->sort_keys; }   // heavy blocks first next time
-    fa.fim21 = nullptr;
-    fa.yaw_only = (c->opt_special && c->yaw_exact) ? 1 : 0;   // the ray-march kernel copies the pose's rotation out of d_yawR
-    rc = maybe_split(c, fa, (size_t)n, false);                // a handful of frontiers: each pose over several workgroups
-    if (rc) return rc;
     bind_fim_outputs(c, fa);
     {
         ScopedTimer t(c, 0);

@@ -60,7 +60,12 @@ def main():
         rec = sc.score_candidates(goals, fsz, bl)
         tag = f"trial {t}: {name} n={n} angle={angle} split={split}"
         ok = arr["status"] == 0
-        assert np.array_equal(rec["arrival"], arr["arrival"]) and np.array_equal(rec["argmax"], arr["argmax"]), tag
+        if not (np.array_equal(rec["arrival"], arr["arrival"]) and np.array_equal(rec["argmax"], arr["argmax"])):
+            bad = np.flatnonzero((rec["arrival"] != arr["arrival"]) | (rec["argmax"] != arr["argmax"]))
+            again = sc.score_arrival(goals, fsz, bl)
+            raise AssertionError((tag, bad.tolist(), rec["arrival"][bad].tolist(), arr["arrival"][bad].tolist(), rec["argmax"][bad].tolist(), arr["argmax"][bad].tolist(),
+                                  fs.capi.record_status(rec)[bad].tolist(), arr["status"][bad].tolist(), goals[bad].tolist(), pick[bad].tolist(),
+                                  "score_arrival:", again["arrival"][bad].tolist(), again["argmax"][bad].tolist()))
         assert np.array_equal(fs.capi.record_status(rec), arr["status"]) and np.array_equal(fs.capi.record_achievable(rec), arr["achievable"]), tag
         assert np.array_equal(rec["n_visible"][ok], fim["n_visible"][ok]), tag
         assert np.array_equal(fs.capi.record_nvoxels(rec)[ok], np.minimum(fim["n_voxels"][ok], 65535)), tag

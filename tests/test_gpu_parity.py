@@ -267,6 +267,41 @@ def test_fused_scoring_of_a_few_frontiers_spreads_each_pose_over_workgroups(fs, 
         scorer.set_fim_params(14.0, 1.0)
 
 
+@pytest.mark.parametrize("name,n", [("C2", 17), ("REF2D", 9), ("REF2D", 33)])
+def test_first_call_of_a_fresh_context_is_a_split_short_list(fs, oracle, ref_table, name, n):
+    """The very FIRST scoring call of a context is a short list whose poses are spread over several workgroups: the per-item
+    scratch (n * W items) outgrows what the call's first sizing (n candidates, 64 elements at least) allocated, so every
+    per-candidate column moves while the call is being set up.  The ray-march kernel and the finish kernel must both see the
+    columns where they ended up (round 5: fs_score_candidates_dev bound the ray-march outputs before the split had grown the
+    columns — arrival 0 and stale argmax in every record; found by tests/fused_random.py, trial 6 of seed 3).  Same for
+    fs_score_fim asking for the 6x6 upper triangles."""
+    w = fs.synth.make_workload(name, n_cand=40)
+    G, P = _oracle_grid_params(oracle, w)
+    mx = oracle.max_arrival_information(G, P)
+    arr = oracle.arrival_information(G, P, w.goals[:n], w.frontier_size[:n], w.blacklisted[:n], min_gt=mx["min_gt"], n_threads=8)
+    poses = oracle.poses_from_yaw(w.goals[:n], arr["yaw"])
+    fim = oracle.pose_information(ref_table, w.landmarks, poses, 14.0, 1.0, n_threads=8)
+    ok = arr["status"] == 0
+    for first in ("fused", "fim21"):
+        sc = fs.FrontierScorer(0)                                    # fresh: nothing has sized the scratch yet
+        try:
+            _setup_scorer(sc, w)
+            sc.lookup_generate()
+            sc.set_arrival_limits(mx["max_gt"], mx["min_gt"])
+            if first == "fim21":
+                full = sc.score_fim(poses)
+                _check_fim(full, fim, w.landmarks.shape[0])
+            rec = sc.score_candidates(w.goals[:n], w.frontier_size[:n], w.blacklisted[:n])
+            np.testing.assert_array_equal(rec["arrival"], arr["arrival"])
+            np.testing.assert_array_equal(rec["argmax"], arr["argmax"])
+            np.testing.assert_array_equal(fs.capi.record_status(rec), arr["status"])
+            np.testing.assert_array_equal(rec["n_visible"][ok], fim["n_visible"][ok])
+            scale = np.maximum(np.abs(fim["info_f64"][ok]), 1e-6)
+            assert np.max(np.abs(rec["info_ref"][ok] - fim["info_f64"][ok]) / scale, initial=0.0) <= REL
+        finally:
+            sc.close()
+
+
 def test_split_pose_that_overflows_goes_to_the_hbm_tier_whole(fs, oracle, scorer, ref_table):
     """A split workgroup sizes its table for its share of the landmarks scanned, so it overflows only where even that share holds
     more distinct voxels than the largest LDS table has slots.  Poses in a sparse half ball of 200 k landmarks show > 2 x 16 384
