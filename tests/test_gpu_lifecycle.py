@@ -9,12 +9,15 @@ grown, so none of them could see it.  The property here needs no oracle: the war
 parity with the oracle is what test_gpu_parity.py establishes); integers must agree bit for bit, float columns within 1e-5 relative
 (the order of racing LDS atomics and the learnt voxel ratio move last bits from call to call — DESIGN.md 4.2).
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 FLT = 1e-5
+TRIALS = int(os.environ.get("FS_LIFECYCLE_TRIALS", "10"))      # fresh contexts per case (by hand: hundreds)
 
 
 def _params(w):
@@ -119,7 +122,7 @@ def test_fresh_context_equals_a_warmed_one_over_random_call_sequences(fs, name, 
         for kind in KINDS:
             for split in (4, 0):
                 _call(fs, warm, kind, w, everything, poses, split, 4.0)
-        for trial in range(10):
+        for trial in range(TRIALS):
             fresh, _ = _make(fs, w, limits)
             try:
                 for step in range(int(rng.integers(2, 7))):
@@ -148,7 +151,7 @@ def test_fresh_multi_context_equals_a_warmed_single_one(fs):
         first = warm.score_arrival(w.goals, w.frontier_size, w.blacklisted)
         poses = fs.synth.poses_from_yaw(w.goals, first["yaw"])
         for devices in ((0, 0), (0, 0, 0)):
-            for trial in range(3):
+            for trial in range(max(3, TRIALS // 3)):
                 m = fs.MultiScorer(devices=devices)
                 try:
                     m.set_ray_params(**_params(w)); m.upload_grid(w.cells, w.origin, w.resolution)
