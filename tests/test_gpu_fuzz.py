@@ -1,12 +1,16 @@
 """Randomised differential test: random grids, fans, visitors, clouds and visibility volumes through the C ABI against the
 oracle.  Same bar as test_gpu_parity.py: integers bit-exact, Fisher information within 1e-4."""
 import importlib
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 REL = 1e-4
+# by hand, for a wider sweep than the suite's 150 configurations: FS_FUZZ_SEEDS=3000 FS_FUZZ_BASE=100000 python -m pytest tests/test_gpu_fuzz.py -m gpu
+N_SEEDS = int(os.environ.get("FS_FUZZ_SEEDS", "150"))
+SEED_BASE = 9000 + int(os.environ.get("FS_FUZZ_BASE", "0"))
 
 
 def _random_case(rng, fs):
@@ -47,9 +51,9 @@ def _random_case(rng, fs):
                 achin=(rng.random(n) < 0.9).astype(np.uint8))
 
 
-@pytest.mark.parametrize("seed", range(150))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_configuration(fs, oracle, scorer, ref_table, seed):
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(SEED_BASE + seed)
     k = _random_case(rng, fs)
     G = oracle.Grid(k["cells"], origin=k["origin"], resolution=k["res"])
     P = oracle.RayParams(**k["ray"])
