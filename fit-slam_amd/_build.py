@@ -32,6 +32,8 @@ DEV_FLAGS = []
 if os.environ.get("FS_BOUNDS"):           # range-checked global accesses in the FIM (counter 30) and ray (29) kernels
     DEV_FLAGS += ["-DFS_FIM_BOUNDS", "-DFS_RAY_BOUNDS"]
     RESOURCE_LIMITS = {}                  # (the checks cost registers: a few bytes of scratch are fine in this build)
+if os.environ.get("FS_POISON"):           # growing buffers are retired (never freed) and 0xCD-filled: stale pointers and reads of fresh memory show
+    DEV_FLAGS.append("-DFS_POISON")
 if os.environ.get("FS_T1_WAVES_PER_EU"):  # occupancy target of the FIM worker's register allocation
     DEV_FLAGS.append("-DFS_T1_WAVES_PER_EU=" + os.environ["FS_T1_WAVES_PER_EU"])
     RESOURCE_LIMITS = {}

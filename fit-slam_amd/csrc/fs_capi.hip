@@ -28,6 +28,21 @@ std::atomic<uint64_t> fs_alloc_generation{0};     // (atomic: fs_multi stages it
 
 namespace {
 
+// Development build FS_POISON (`FS_POISON=1 python fit-slam_amd/_build.py`, a library of its own like every FS_DEV build): a
+// buffer that grows is RETIRED, not freed — nothing allocated later can land on its address — and both the retired and the new
+// memory are filled with 0xCD.  A launch that still holds a pointer taken before the growth then writes where nobody reads, and
+// whoever reads the new buffer finds the pattern instead of a result: the stale-pointer defect of round 5 (fs_score_candidates_dev,
+// DESIGN.md 0) fails every time under this build instead of only when the allocator happens to hand out a different address;
+// so does anything that relies on fresh device memory being zero.  Leaks by design; test processes only.
+#ifdef FS_POISON
+static void poison_device(void *p, size_t bytes)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(p, 0xCD, bytes);
+    (void)hipDeviceSynchronize();
+}
+#endif
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -35,12 +50,19 @@ struct DevBuf {
     hipError_t ensure(size_t n)
     {
         if (n <= cap) return hipSuccess;
+#ifdef FS_POISON
+        if (p) poison_device(p, cap * sizeof(T));                 // retired
+#else
         if (p) (void)hipFree(p);
+#endif
         p = nullptr; cap = 0;
         size_t want = std::max<size_t>(n, 64);
         ++fs_alloc_generation;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
         if (e == hipSuccess) cap = want;
+#ifdef FS_POISON
+        if (e == hipSuccess) poison_device(p, want * sizeof(T));
+#endif
         return e;
     }
     void release()
@@ -63,11 +85,18 @@ struct PinnedBuf {
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
+#ifdef FS_POISON
+        if (p) { (void)hipDeviceSynchronize(); std::memset(p, 0xCD, cap); }      // retired (see DevBuf)
+#else
         if (p) (void)hipHostFree(p);
+#endif
         p = nullptr; dev = nullptr; cap = 0;
         const size_t want = std::max<size_t>(bytes, 4096);
         ++fs_alloc_generation;
         hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p), want, hipHostMallocMapped);
+#ifdef FS_POISON
+        if (e == hipSuccess) std::memset(p, 0xCD, want);
+#endif
         if (e != hipSuccess) {
             // a runtime / device that refuses MAPPED page-locked memory still gets plain page-locked staging: dev stays nullptr and
             // every entry point takes its transfer path (the sticky error of the refused call is cleared first)
