@@ -131,7 +131,13 @@ def test_fresh_context_equals_a_warmed_one_over_random_call_sequences(fs, name, 
                     pick = rng.choice(w.goals.shape[0], size=n, replace=False)
                     split = int(rng.choice([0, 1, 2, 3, 4, 5]))
                     angle = float(rng.choice([0.6, 1.0, 1.3, 4.0]))
-                    what = f"{name} seed {seed} trial {trial} step {step}: {kind} n={n} split={split} angle={angle}"
+                    # the fresh context also takes the optional routes of the small calls: captured launch graphs, transfers instead
+                    # of the mapped page-locked buffers, the finish kernel instead of the host-side finish (the warmed one stays on
+                    # the defaults: same results whatever the route)
+                    opts = {k: int(rng.integers(0, 2)) for k in ("graph", "zerocopy", "fim.hostfinish")}
+                    for k, v in opts.items():
+                        fresh.set_option(k, v)
+                    what = f"{name} seed {seed} trial {trial} step {step}: {kind} n={n} split={split} angle={angle} {opts}"
                     got = _call(fs, fresh, kind, w, pick, poses, split, angle)
                     want = _call(fs, warm, kind, w, pick, poses, split, angle)
                     _compare(fs, kind, got, want, what)
