@@ -10,6 +10,8 @@ parity with the oracle is what test_gpu_parity.py establishes); integers must ag
 (the order of racing LDS atomics and the learnt voxel ratio move last bits from call to call — DESIGN.md 4.2).
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -178,3 +180,27 @@ def test_fresh_multi_context_equals_a_warmed_single_one(fs):
                     m.close()
     finally:
         warm.close()
+
+
+def test_fresh_context_tests_under_the_poison_build():
+    """The fresh-context tests once more, in a child process, against the FS_POISON development library (fs_capi.hip: a buffer that
+    grows is retired instead of freed and both copies are filled with 0xCD — a pointer taken before the growth then fails every
+    time, not only when the allocator happens to hand out another address; __graft_entry__.build() pre-builds that library so
+    that it travels with the tree).  The pre-fix sources of round 5 fail all eight of them under it
+    (profiles/r05/lifecycle/poison_build_before_fix.log)."""
+    if os.environ.get("FS_POISON"):
+        pytest.skip("this process already runs the poison build")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FS_POISON="1", FS_LIFECYCLE_TRIALS="6")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_lifecycle.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", "fresh_context or fresh_multi or first_call_of_a_fresh"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert " passed" in r.stdout and "libfitslam_frontier_dev" in _poison_library(env, root), r.stdout[-2000:]
+
+
+def _poison_library(env, root):
+    """the library file a process with this environment loads (the development builds have names of their own)"""
+    out = subprocess.run([sys.executable, "-c", "import importlib,sys; sys.path.insert(0, sys.argv[1]); print(importlib.import_module('fit-slam_amd._build').LIB)", root],
+                         env=env, stdout=subprocess.PIPE, text=True, timeout=120)
+    return out.stdout.strip()

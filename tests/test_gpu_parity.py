@@ -274,7 +274,9 @@ def test_first_call_of_a_fresh_context_is_a_split_short_list(fs, oracle, ref_tab
     per-candidate column moves while the call is being set up.  The ray-march kernel and the finish kernel must both see the
     columns where they ended up (round 5: fs_score_candidates_dev bound the ray-march outputs before the split had grown the
     columns — arrival 0 and stale argmax in every record; found by tests/fused_random.py, trial 6 of seed 3).  Same for
-    fs_score_fim asking for the 6x6 upper triangles."""
+    fs_score_fim asking for the 6x6 upper triangles.  (With the production library this catches the defect only when the allocator
+    hands the grown column a new address — it often re-uses the block it just got back; under the FS_POISON development build,
+    which retires grown buffers, it fails every time: tests/test_gpu_lifecycle.py runs it there in a child process.)"""
     w = fs.synth.make_workload(name, n_cand=40)
     G, P = _oracle_grid_params(oracle, w)
     mx = oracle.max_arrival_information(G, P)
