@@ -13,7 +13,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libfso_oracle.so")
+_SO = os.environ.get("FSO_ORACLE_SO") or os.path.join(_HERE, "libfso_oracle.so")     # (FSO_ORACLE_SO: a sanitizer build of the same sources, by hand)
 
 STATUS_OK, STATUS_OFF_MAP, STATUS_BLACKLISTED = 0, 1, 2
 
