@@ -34,6 +34,11 @@ if os.environ.get("FS_BOUNDS"):           # range-checked global accesses in the
     RESOURCE_LIMITS = {}                  # (the checks cost registers: a few bytes of scratch are fine in this build)
 if os.environ.get("FS_POISON"):           # growing buffers are retired (never freed) and 0xCD-filled: stale pointers and reads of fresh memory show
     DEV_FLAGS.append("-DFS_POISON")
+LINK_FLAGS = []
+if os.environ.get("FS_HOST_ASAN"):        # AddressSanitizer on the HOST side of the library only (-fno-gpu-sanitize: the code objects stay plain gfx950);
+    DEV_FLAGS += ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-g"]   # run with LD_PRELOAD=<clang's libclang_rt.asan-x86_64.so>
+    LINK_FLAGS = ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"]
+    RESOURCE_LIMITS = {}
 if os.environ.get("FS_T1_WAVES_PER_EU"):  # occupancy target of the FIM worker's register allocation
     DEV_FLAGS.append("-DFS_T1_WAVES_PER_EU=" + os.environ["FS_T1_WAVES_PER_EU"])
     RESOURCE_LIMITS = {}
@@ -223,7 +228,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
     # linked under a temporary name and renamed into place: a process that loads the library while another one links never
     # sees a half-written file
     tmp = LIB + f".tmp{os.getpid()}"
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *LINK_FLAGS, "-o", tmp, *objs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr, flush=True)
     subprocess.check_call(cmd, stdout=sys.stderr)
