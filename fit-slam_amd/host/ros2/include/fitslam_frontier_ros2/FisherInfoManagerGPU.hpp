@@ -36,8 +36,9 @@ public:
     // device_ids: HIP ordinals to score on; empty = the node's parameter `fitslam_frontier.gpu_devices` (default [0]) — the same
     // list CostAssignerGPU reads: one isPoseSafe pose runs on the first device, a batch (poseInformation) is cut into one
     // contiguous block per device (fs_multi_score_fim)
+    static constexpr const char *kReferenceLookupFile = "/root/dev_ws/src/lookup_table_fi/fisher_information_lookup_table.dat";   // FisherInfoManager.cpp:120,234
     explicit FisherInformationManagerGPU(std::shared_ptr<nav2_util::LifecycleNode> node, std::vector<int> device_ids = {},
-                                         const std::string &lookup_file = "/root/dev_ws/src/lookup_table_fi/fisher_information_lookup_table.dat");
+                                         const std::string &lookup_file = kReferenceLookupFile);
     ~FisherInformationManagerGPU();
     FisherInformationManagerGPU(const FisherInformationManagerGPU &) = delete;
     FisherInformationManagerGPU &operator=(const FisherInformationManagerGPU &) = delete;

@@ -24,6 +24,13 @@ FisherInformationManagerGPU::FisherInformationManagerGPU(std::shared_ptr<nav2_ut
         node_->get_parameter("fitslam_frontier.gpu_devices", ids);
         for (const int64_t d : ids) device_ids.push_back(static_cast<int>(d));
     }
+    // Where the table lives.  The reference hard-codes the path (FisherInfoManager.cpp:120,234) and that path is the default here;
+    // the node parameter `fisherInformation.lookup_table_file` lets an install that keeps the file elsewhere say so (an explicit
+    // constructor argument wins over it).
+    if (lookup_file_ == kReferenceLookupFile) {
+        if (!node_->has_parameter("fisherInformation.lookup_table_file")) node_->declare_parameter("fisherInformation.lookup_table_file", lookup_file_);
+        node_->get_parameter("fisherInformation.lookup_table_file", lookup_file_);
+    }
     if (fs_multi_create(device_ids.data(), static_cast<int>(device_ids.size()), &scorer_) != FS_OK)
         throw std::runtime_error("fitslam_frontier: no MI355X (gfx950) under one of fitslam_frontier.gpu_devices; there is no CPU fallback");
     // Which landmarks a pose "sees" is the reference's REQUEST to the SLAM server (FisherInfoManager.cpp:63-64):
