@@ -204,3 +204,40 @@ def _poison_library(env, root):
     out = subprocess.run([sys.executable, "-c", "import importlib,sys; sys.path.insert(0, sys.argv[1]); print(importlib.import_module('fit-slam_amd._build').LIB)", root],
                          env=env, stdout=subprocess.PIPE, text=True, timeout=120)
     return out.stdout.strip()
+
+
+def test_two_contexts_from_two_threads_at_once(fs):
+    """The ROS adapter holds two scorer objects — CostAssignerGPU on the behaviour-tree thread, FisherInformationManagerGPU behind its
+    own mutex — so two host threads may be inside the library at the same time, each on a context of its own (a context itself is
+    single-caller: include/fitslam_frontier.h).  Two threads (ctypes releases the interpreter lock during a call), one context each,
+    a few hundred mixed small calls each, at once: every result must be the one a single thread gets."""
+    import threading
+    w = fs.synth.make_workload("REF2D", n_cand=300)
+    ctx, limits = _make(fs, w)
+    other, _ = _make(fs, w, limits)
+    try:
+        first = ctx.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+        poses = fs.synth.poses_from_yaw(w.goals, first["yaw"])
+        rng = np.random.default_rng(3)
+        plan = []
+        for _ in range(150):
+            kind = str(rng.choice(["fused", "costs_fim", "info_only", "fim_full", "arrival"]))
+            n = int(rng.choice([1, 3, 9, 33, 120, 300]))
+            plan.append((kind, rng.choice(w.goals.shape[0], size=n, replace=False), int(rng.choice([0, 3])), float(rng.choice([1.0, 4.0]))))
+        want = [_call(fs, ctx, k, w, pick, poses, split, angle) for k, pick, split, angle in plan]       # single-threaded reference
+        errors = []
+
+        def run(scorer, order):
+            try:
+                for i in order:
+                    k, pick, split, angle = plan[i]
+                    _compare(fs, k, _call(fs, scorer, k, w, pick, poses, split, angle), want[i], f"thread call {i}: {k} n={len(pick)}")
+            except BaseException as e:                       # noqa: BLE001  (reported by the main thread)
+                errors.append(e)
+
+        a = threading.Thread(target=run, args=(ctx, list(range(len(plan)))))
+        b = threading.Thread(target=run, args=(other, list(reversed(range(len(plan))))))
+        a.start(); b.start(); a.join(); b.join()
+        assert not errors, errors[0]
+    finally:
+        ctx.close(); other.close()
