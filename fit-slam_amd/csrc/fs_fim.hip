@@ -33,6 +33,8 @@
 // real overflow hands it to the table in HBM.  Scan + scatter-count has no dense contraction: no MFMA.
 #include "fs_internal.h"
 
+#include <atomic>
+
 #define FS_NACC 18       // info, 15 FIM block sums, n_visible, n_voxels
 #define FS_QCAP 128      // per-wave compaction queue (<= 63 left over + 64 new)
 #define FS_MAX_PROBE 64  // LDS tiers give up (-> next tier) after this many bucket visits
@@ -1191,9 +1193,19 @@ hipError_t launch_tier1(FsFimArgs &a, hipStream_t s)
     auto kernel = fs_fim_kernel<FS_T1_THREADS, TABLE_FULL, CONE, INFO_ONLY, YAW_ONLY, SPLIT>;
     hipError_t e = allow_lds(kernel, lds);
     if (e != hipSuccess) return e;
-    static int resident = 0;                                   // same kernel, same LDS budget class: query once (per instantiation)
-    static size_t resident_lds = 0;
-    if (resident == 0 || resident_lds != lds) { resident = resident_blocks(kernel, FS_T1_THREADS, lds); resident_lds = lds; }
+    // same kernel, same device, same LDS budget class: the occupancy query is made once (per instantiation) and remembered in ONE
+    // atomic word — (device, LDS bytes, resident workgroups) — because contexts on different host threads launch through here at
+    // the same time ("Threads"): a reader sees a complete triple or recomputes, never half of an update
+    static std::atomic<uint64_t> cache{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = ((uint64_t)(dev & 0xff) << 44) | ((uint64_t)lds << 20);
+    uint64_t seen = cache.load(std::memory_order_relaxed);
+    if ((seen & ~0xfffffull) != key || (seen & 0xfffffull) == 0) {
+        seen = key | (uint64_t)(resident_blocks(kernel, FS_T1_THREADS, lds) & 0xfffff);
+        cache.store(seen, std::memory_order_relaxed);
+    }
+    const int resident = (int)(seen & 0xfffffull);
     hipLaunchKernelGGL(kernel, dim3(a.cand_count < resident ? a.cand_count : resident), dim3(FS_T1_THREADS), lds, s, a);
     return hipGetLastError();
 }

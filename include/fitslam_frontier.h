@@ -14,6 +14,7 @@
  *     the last failure on a context is available from fs_last_error().
  *   - a context is single-caller (externally synchronised), owns one HIP stream (or borrows the
  *     one passed at creation) and owns device copies of grid, landmarks and lookup table.
+ *     DIFFERENT contexts may be used from different host threads at the same time.
  *     Host buffers stay caller-owned; nothing is allocated across the ABI.
  *   - grid layout [nz][ny][nx] uint8, index = (z*ny + y)*nx + x; nz == 1 is the reference's
  *     nav2_costmap_2d::Costmap2D (cost constants: 255 unknown, 254 lethal, 253 inscribed, 0 free).
