@@ -111,3 +111,46 @@ def test_processing_order_never_changes_a_record(fs):
         assert _same_records(s.score_candidates(w.goals, w.frontier_size, w.blacklisted), ref)
     finally:
         s.close()
+
+
+def test_landmark_cloud_at_the_documented_maximum(fs, oracle, ref_table):
+    """The largest cloud a context takes is 2 000 000 landmarks (fs_upload_landmarks; four times configs[4]'s 500 k): at exactly
+    the maximum every column of fs_score_fim and the info-only call must still be the oracle's — a clumped cloud, so that chunks
+    of very different sizes, multi-pass poses and the HBM tier all occur — and one landmark more is refused with FS_E_INVALID,
+    the staged cloud left as it was."""
+    rng = np.random.default_rng(2_000_000)
+    m = 2_000_000
+    lm = rng.uniform(-40.0, 40.0, size=(m, 3)).astype(np.float32)
+    lm[:, 2] = rng.uniform(-2.0, 3.0, size=m)
+    lm[:300_000] = (np.array([6.0, 1.0, 0.5]) + rng.normal(scale=1.2, size=(300_000, 3))).astype(np.float32)      # a dense clump
+    poses = np.zeros((10, 7)); poses[:, 6] = 1.0
+    poses[:, 0] = np.linspace(-30.0, 30.0, 10); poses[:, 1] = np.linspace(-5.0, 5.0, 10)
+    poses[4, :3] = (2.0, 1.0, 0.5)                                       # looking into the clump
+    q = rng.normal(size=(3, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses[7:, 3:] = q                                                    # three general orientations
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.lookup_generate()
+        s.upload_landmarks(lm)
+        parity = __import__("importlib").import_module("fit-slam_amd.parity")
+        for angle in (1.0, 4.0):
+            s.set_fim_params(14.0, angle)
+            want = oracle.pose_information(ref_table, lm, poses, 14.0, angle, n_threads=16)
+            assert want["n_visible"].max() > 100_000 and want["n_voxels"].max() > 16384
+            got = s.score_fim(poses)
+            np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
+            np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
+            sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
+            assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= 1e-4
+            assert np.max(np.abs(got["trace"] - want["trace"]) / np.maximum(np.abs(want["trace"]), 1e-6)) <= 1e-4
+            gate = parity.logdet_gate(got["logdet"], want["logdet"], want["fim"], n_visible=want["n_visible"])
+            assert gate["ok"], gate
+            only = s.score_fim(poses, info_only=True)
+            np.testing.assert_array_equal(only["n_voxels"], want["n_voxels"])
+            assert np.max(np.abs(only["info_ref"] - want["info_f64"]) / sc) <= 1e-4
+        with pytest.raises(fs.FsError):
+            s.upload_landmarks(np.concatenate([lm, lm[:1]]))
+        again = s.score_fim(poses[:2], info_only=True)                   # the refused upload left the staged cloud alone
+        np.testing.assert_array_equal(again["n_voxels"], want["n_voxels"][:2])
+    finally:
+        s.close()
