@@ -154,3 +154,65 @@ def test_landmark_cloud_at_the_documented_maximum(fs, oracle, ref_table):
         np.testing.assert_array_equal(again["n_voxels"], want["n_voxels"][:2])
     finally:
         s.close()
+
+
+def test_ray_fan_at_the_documented_maxima(fs, oracle):
+    """4096 yaw rays (fs_set_ray_params' limit) x 16 elevation rings (FS_MAX_ELEV) = 65 536 rays per candidate on a 3-D grid:
+    per-ray counts, window maximum, first argmax, yaw and achievability against the oracle; 4097 rays and 17 rings are refused."""
+    w = fs.synth.make_workload("C1", n_cand=24)
+    n_yaw = 4096
+    elev = tuple(np.linspace(-0.45, 0.45, 16).tolist())
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=2 * np.pi / n_yaw, camera_fov=w.camera_fov, robot_radius=w.robot_radius,
+              n_rays=n_yaw, elev=elev, polygon=w.polygon)
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.set_ray_params(**kw)
+        assert (s.n_yaw, s.n_elev, s.window) == (4096, 16, int(w.camera_fov / (2 * np.pi / n_yaw)))
+        s.upload_grid(w.cells, w.origin, w.resolution)
+        G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
+        P = oracle.RayParams(**kw)
+        mx = oracle.max_arrival_information(G, P)
+        assert s.max_arrival() == mx
+        want = oracle.arrival_information(G, P, w.goals, w.frontier_size, w.blacklisted, min_gt=mx["min_gt"], n_threads=16)
+        got = s.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+        for k in ("status", "arrival", "argmax", "achievable", "ray_counts"):
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+        np.testing.assert_array_equal(got["yaw"], want["yaw"])
+        assert want["arrival"].max() > 10_000 and got["ray_counts"].shape == (24, 16, 4096)
+        with pytest.raises(fs.FsError):
+            s.set_ray_params(**dict(kw, n_rays=4097, delta_theta=2 * np.pi / 4097))
+        with pytest.raises(fs.FsError):
+            s.set_ray_params(**dict(kw, elev=tuple(np.linspace(-0.45, 0.45, 17).tolist())))
+    finally:
+        s.close()
+
+
+def test_lookup_table_at_the_documented_maximum(fs, oracle):
+    """The dense lattice table holds up to 2^21 - 2 cells (the voxel key shares a 32-bit slot word with an 11-bit count): a table of
+    127 x 128 x 128 = 2 080 768 cells — three times the reference's 71 x 100 x 100 — generated on both sides byte for byte, then
+    scored; a lattice over the limit is refused."""
+    step = 0.3
+    bounds = (0.0, 125 * step + 0.01, -63 * step + 0.01, 63 * step + 0.01, -63 * step + 0.01, 63 * step + 0.01)
+    t = oracle.Table.generate(bounds)
+    assert t.records.shape[0] == 127 * 128 * 128
+    rng = np.random.default_rng(21)
+    lm = rng.uniform(-30.0, 30.0, size=(150_000, 3)).astype(np.float32)
+    poses = np.zeros((6, 7)); poses[:, 6] = 1.0
+    poses[:, 0] = np.linspace(-10.0, 10.0, 6)
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.lookup_generate(bounds)
+        assert s.lookup_records().tobytes() == t.records.tobytes()
+        s.upload_landmarks(lm)
+        s.set_fim_params(40.0, 4.0)                                       # a range that reaches the far end of the table
+        want = oracle.pose_information(t, lm, poses, 40.0, 4.0, n_threads=16)
+        got = s.score_fim(poses)
+        np.testing.assert_array_equal(got["n_voxels"], want["n_voxels"])
+        np.testing.assert_array_equal(got["n_visible"], want["n_visible"])
+        sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
+        assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= 1e-4
+        assert want["n_voxels"].max() > 16384
+        with pytest.raises(fs.FsError):
+            s.lookup_generate((0.0, 127 * step + 0.01, -64 * step + 0.01, 63 * step + 0.01, -63 * step + 0.01, 63 * step + 0.01))     # 129 x 129 x 128 = 2 130 048 > 2^21 - 2
+    finally:
+        s.close()
