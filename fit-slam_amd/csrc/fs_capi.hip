@@ -1367,7 +1367,8 @@ void fs_stage_landmarks(const float *xyz, int32_t m, FsStagedCloud &out)
         int32_t tail = m;
         for (int32_t i = 0; i < m; ++i) {
             const float *p = xyz + 3 * (size_t)i;
-            if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2])) order[n_finite++] = i;
+            // (usable: finite and within 1e17 m of the origin — see below; fabsf of a NaN compares false)
+            if (std::fabs(p[0]) <= 1.0e17f && std::fabs(p[1]) <= 1.0e17f && std::fabs(p[2]) <= 1.0e17f) order[n_finite++] = i;
             else order[--tail] = i;
         }
         std::reverse(order.begin() + n_finite, order.end());      // keep the non-finite ones in input order
@@ -1403,7 +1404,15 @@ void fs_stage_landmarks(const float *xyz, int32_t m, FsStagedCloud &out)
     // SoA + far-away sentinels in the padding: (1e18)^2 is finite in fp32 and beyond any max_dist^2
     std::vector<float> &x = out.x, &y = out.y, &z = out.z, &sph = out.sph;
     x.assign(mp, 1.0e18f); y.assign(mp, 1.0e18f); z.assign(mp, 1.0e18f); sph.assign((size_t)n_chunks * 4, 0.0f);
-    for (int32_t i = 0; i < m; ++i) {
+    // A point with a NaN or an infinite coordinate lies outside every visibility volume (n^2 <= max_dist^2 is false for it), and the
+    // kernels must never see it: their cone predicate is ONE v_min3_f32, which DROPS a NaN operand — a landmark at x = +inf seen from
+    // a pose whose rotation has exact zeros (px = +inf, py = 0 * inf = NaN, n^2 = NaN) would pass as visible (found in round 5 by
+    // tests/test_gpu_hardening.py::test_non_finite_and_far_away_landmarks_are_never_visible).  Such points keep their slots (the
+    // cloud's size and order are the caller's) but are staged as the far-away sentinel of the padding.  The same for a FINITE
+    // coordinate beyond 1e17 m: rotated into a camera frame it can overflow fp32 to +-inf, and an invisible landmark's terms are
+    // removed by a factor q = 0, which inf * 0 = NaN defeats (NaN in the 6x6 sums of every pose with a general rotation).  Nothing
+    // that far out is within any range fs_set_fim_params accepts (max_dist < 1e9 m).
+    for (int32_t i = 0; i < n_finite; ++i) {
         const float *p = xyz + 3 * (size_t)order[i];
         x[i] = p[0]; y[i] = p[1]; z[i] = p[2];
     }
@@ -1412,7 +1421,7 @@ void fs_stage_landmarks(const float *xyz, int32_t m, FsStagedCloud &out)
         int cnt = 0;
         for (int k = 0; k < FS_CHUNK; ++k) {
             const size_t i = (size_t)ch * FS_CHUNK + k;
-            if (i >= (size_t)m || !std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i])) continue;
+            if (i >= (size_t)n_finite) continue;                  // (padding and the non-finite points: sentinels, in no sphere)
             const double p[3] = {x[i], y[i], z[i]};
             for (int a = 0; a < 3; ++a) { blo[a] = std::min(blo[a], p[a]); bhi[a] = std::max(bhi[a], p[a]); }
             ++cnt;
@@ -1423,7 +1432,7 @@ void fs_stage_landmarks(const float *xyz, int32_t m, FsStagedCloud &out)
         double r2 = 0.0;
         for (int k = 0; k < FS_CHUNK; ++k) {
             const size_t i = (size_t)ch * FS_CHUNK + k;
-            if (i >= (size_t)m || !std::isfinite(x[i]) || !std::isfinite(y[i]) || !std::isfinite(z[i])) continue;
+            if (i >= (size_t)n_finite) continue;                  // (padding and the non-finite points: sentinels, in no sphere)
             const double dx = (double)x[i] - ctr[0], dy = (double)y[i] - ctr[1], dz = (double)z[i] - ctr[2];
             r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
         }
@@ -1589,6 +1598,8 @@ int fs_set_fim_params(fs_ctx *c, const fs_fim_params *p)
 {
     if (!c || !p) return FS_E_INVALID;
     if (!(p->max_dist > 0.0) || !(p->max_angle > 0.0)) return fail(c, FS_E_INVALID, "max_dist and max_angle must be positive");
+    // (the padding of the landmark arrays and every unusable landmark sit at 1e18 m: max_dist^2 must stay far below (1e18)^2 in fp32)
+    if (!(p->max_dist < 1.0e9)) return fail(c, FS_E_INVALID, "max_dist must be below 1e9 m");
     if (p->max_dist != c->fp.max_dist || p->max_angle != c->fp.max_angle) reset_voxel_ratio(c);
     c->fp = *p;
     ++c->epoch;

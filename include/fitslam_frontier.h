@@ -74,7 +74,7 @@ typedef struct {
 /* Replaces the GetLandmarksInView request fields (FIP/src/fisher_information/FisherInfoManager.cpp:60-65)
  * by an explicit visibility predicate (DESIGN.md "Visibility"). */
 typedef struct {
-    double max_dist;             /* 14.0 */
+    double max_dist;             /* 14.0; must be positive and below 1e9 m */
     double max_angle;            /* 1.0 rad from the camera +x axis; >= pi disables the cone */
 } fs_fim_params;
 
@@ -195,7 +195,8 @@ int fs_trace_segments(fs_ctx *ctx, int32_t n, const double *start_xyz, const dou
 /* ---------------------------------------------------------------- Fisher information */
 
 /* Replaces the per-query service response `map_points` (FIP/src/.../FisherInfoManager.cpp:60-88)
- * by the whole landmark cloud staged once: xyz [m][3] float32, world frame. */
+ * by the whole landmark cloud staged once: xyz [m][3] float32, world frame.  A point with a NaN / infinite coordinate, or one
+ * beyond 1e17 m, is visible from nowhere; it keeps its place in the count m and contributes to no pose. */
 int fs_upload_landmarks(fs_ctx *ctx, const float *xyz, int32_t m);
 
 /* Replaces generateLookupTable(minX,maxX,minY,maxY,minZ,maxZ) (FIP/include/.../FisherInfoManager.hpp:94,

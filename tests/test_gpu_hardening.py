@@ -216,3 +216,96 @@ def test_lookup_table_at_the_documented_maximum(fs, oracle):
             s.lookup_generate((0.0, 127 * step + 0.01, -64 * step + 0.01, 63 * step + 0.01, -63 * step + 0.01, 63 * step + 0.01))     # 129 x 129 x 128 = 2 130 048 > 2^21 - 2
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("angle", [1.0, 4.0])
+def test_non_finite_and_far_away_landmarks_are_never_visible(fs, oracle, ref_table, angle):
+    """A cloud with NaN, +-inf and 1e30 coordinates sprinkled over it (a SLAM front end that has not culled its map): such a point is
+    outside every visibility volume — the predicate n^2 <= max_dist^2 is false for it — so every column must equal the oracle's on
+    the same cloud AND the columns of the cloud without those points; the k-d ordering (a comparator over coordinates) must not
+    see them (fs_stage_landmarks puts them behind the finite ones)."""
+    rng = np.random.default_rng(77)
+    clean = rng.uniform(-8.0, 8.0, size=(6000, 3)).astype(np.float32)
+    dirty = np.repeat(clean, 1, axis=0)
+    bad = np.array([[np.nan, 0, 0], [0, np.nan, 1], [1, 2, np.nan], [np.inf, 0, 0], [0, -np.inf, 0], [np.nan, np.nan, np.nan],
+                    [1e30, 0, 0], [0, -1e30, 1e30], [3.0e38, 3.0e38, 3.0e38]], dtype=np.float32)
+    where = rng.choice(6000, size=400, replace=False)
+    dirty = np.insert(dirty, where, bad[rng.integers(0, len(bad), size=400)], axis=0)
+    poses = np.zeros((12, 7)); poses[:, 6] = 1.0
+    poses[:, :2] = rng.uniform(-5.0, 5.0, size=(12, 2))
+    q = rng.normal(size=(4, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses[8:, 3:] = q
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.lookup_generate()
+        s.set_fim_params(14.0, angle)
+        s.upload_landmarks(clean)
+        base = s.score_fim(poses)
+        s.upload_landmarks(dirty)
+        got = s.score_fim(poses)
+        only = s.score_fim(poses, info_only=True)
+        with np.errstate(all="ignore"):
+            want = oracle.pose_information(ref_table, dirty, poses, 14.0, angle, n_threads=8)
+        for k in ("n_visible", "n_voxels"):
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+            np.testing.assert_array_equal(got[k], base[k], err_msg=k)
+        np.testing.assert_array_equal(only["n_voxels"], want["n_voxels"])
+        sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
+        assert np.all(np.isfinite(got["info_ref"])) and np.all(np.isfinite(got["trace"])) and np.all(np.isfinite(got["fim21"]))
+        assert np.max(np.abs(got["info_ref"] - want["info_f64"]) / sc) <= 1e-4
+        assert np.max(np.abs(only["info_ref"] - want["info_f64"]) / sc) <= 1e-4
+        assert np.max(np.abs(got["info_ref"] - base["info_ref"]) / sc) <= 1e-5
+        assert want["n_visible"].min() > 100
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("angle", [1.0, 4.0])
+def test_unusable_poses_spoil_only_themselves(fs, oracle, ref_table, angle):
+    """Poses nobody can stand at — NaN or infinite position, a position 1e30 m out, a NaN quaternion (and an all-zero one, which Eigen and the oracle read as the identity) — mixed into a batch
+    of sound ones, through every column, the info-only call and a short (split) list: the call returns, nothing is read or
+    written out of range (tests run under the FS_BOUNDS build too), the sound poses get exactly the results they get without the
+    others, and an unusable pose sees nothing (no landmark is within range of it) or NaN — never a count out of thin air."""
+    rng = np.random.default_rng(5)
+    lm = rng.uniform(-8.0, 8.0, size=(20000, 3)).astype(np.float32)
+    sound = np.zeros((6, 7)); sound[:, 6] = 1.0
+    sound[:, :2] = rng.uniform(-4.0, 4.0, size=(6, 2))
+    q = rng.normal(size=(3, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    sound[3:, 3:] = q
+    bad = np.zeros((7, 7)); bad[:, 6] = 1.0
+    bad[0, 0] = np.nan; bad[1, 1] = np.inf; bad[2, 2] = -np.inf; bad[3, :3] = 1e30
+    bad[4, 3:] = np.nan; bad[5, 3:] = 0.0; bad[6, :3] = (3e38, -3e38, 3e38)
+    mixed = np.concatenate([sound[:3], bad, sound[3:]])
+    where_sound = np.r_[0:3, 10:13]
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.lookup_generate()
+        s.upload_landmarks(lm)
+        s.set_fim_params(14.0, angle)
+        want = oracle.pose_information(ref_table, lm, sound, 14.0, angle, n_threads=8)
+        sc = np.maximum(np.abs(want["info_f64"]), 1e-6)
+        for batch, idx in ((mixed, where_sound), (mixed[1:5], np.r_[0:2]), (mixed[2:4], np.r_[0:1])):
+            base = sound[:3][-len(idx):] if len(idx) < 3 else sound
+            exp = {k: (v[:3][-len(idx):] if len(idx) < 3 else v) for k, v in want.items()}
+            got = s.score_fim(batch)
+            only = s.score_fim(batch, info_only=True)
+            np.testing.assert_array_equal(got["n_visible"][idx], exp["n_visible"])
+            np.testing.assert_array_equal(got["n_voxels"][idx], exp["n_voxels"])
+            np.testing.assert_array_equal(only["n_voxels"][idx], exp["n_voxels"])
+            e = np.maximum(np.abs(exp["info_f64"]), 1e-6)
+            assert np.max(np.abs(got["info_ref"][idx] - exp["info_f64"]) / e) <= 1e-4
+            assert np.max(np.abs(only["info_ref"][idx] - exp["info_f64"]) / e) <= 1e-4
+            assert np.max(np.abs(got["trace"][idx] - exp["trace"]) / np.maximum(np.abs(exp["trace"]), 1e-6)) <= 1e-4
+            others = np.setdiff1d(np.arange(len(batch)), idx)
+            # (an all-zero quaternion is a rotation to Eigen — the identity, FisherInformationHelpers.cpp:20-24 — and to the oracle: it
+            # is a sound pose at the origin, checked as such)
+            zero_q = np.array([k for k in others if not np.any(batch[k, 3:]) and np.all(np.isfinite(batch[k, :3]))], dtype=int)
+            if len(zero_q):
+                z = oracle.pose_information(ref_table, lm, batch[zero_q], 14.0, angle, n_threads=2)
+                np.testing.assert_array_equal(got["n_visible"][zero_q], z["n_visible"])
+                assert np.max(np.abs(got["info_ref"][zero_q] - z["info_f64"]) / np.maximum(np.abs(z["info_f64"]), 1e-6)) <= 1e-4
+            rest = np.setdiff1d(others, zero_q)
+            assert np.all((got["n_visible"][rest] == 0) | ~np.isfinite(got["info_ref"][rest])), got["n_visible"][rest]
+            assert np.all((only["info_ref"][rest] == 0) | ~np.isfinite(only["info_ref"][rest])), only["info_ref"][rest]
+    finally:
+        s.close()
