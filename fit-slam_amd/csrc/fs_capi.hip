@@ -891,6 +891,13 @@ int fs_set_ray_params(fs_ctx *c, const fs_ray_params *p)
     if (!(p->delta_theta > 0.0) || !(p->max_camera_depth > 0.0) || !(p->camera_fov > 0.0))
         return fail(c, FS_E_INVALID, "max_camera_depth, delta_theta and camera_fov must be positive");
     if (p->n_elev < 1 || p->n_elev > FS_MAX_ELEV) return fail(c, FS_E_INVALID, "n_elev must be in [1,%d]", FS_MAX_ELEV);
+    if (!std::isfinite(p->delta_theta) || !std::isfinite(p->max_camera_depth) || !std::isfinite(p->camera_fov) || !std::isfinite(p->robot_radius) ||
+        !(p->robot_radius >= 0.0))
+        return fail(c, FS_E_INVALID, "max_camera_depth, delta_theta, camera_fov and robot_radius must be finite (robot_radius >= 0)");
+    for (int e = 0; e < p->n_elev; ++e)
+        if (!std::isfinite(p->elev[e])) return fail(c, FS_E_INVALID, "elevation angles must be finite");
+    for (int k = 0; k < 4; ++k)
+        if (p->polygon[k] != p->polygon[k]) return fail(c, FS_E_INVALID, "polygon bounds must not be NaN");      // (+-DBL_MAX / +-inf = no clamp)
     // DEP/src/CostCalculator.cpp:36 — accumulated theta, `theta <= 2*pi`
     std::vector<double> theta;
     if (p->n_rays > 0) {
@@ -963,7 +970,9 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
 {
     if (!c || !cells || !origin_xyz) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
+    if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0) || !std::isfinite(resolution)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
+    // (worldToMap with a NaN origin is a float-to-integer conversion of NaN: undefined in the reference, refused here)
+    if (!std::isfinite(origin_xyz[0]) || !std::isfinite(origin_xyz[1]) || !std::isfinite(origin_xyz[2])) return fail(c, FS_E_INVALID, "grid origin must be finite");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
     // (cell offsets are 32-bit unsigned in the walks, one z step is a signed 32-bit stride; everything else indexes in 64 bits)
     if (total >= (1ull << 32) || (uint64_t)nx * (uint64_t)ny >= (1ull << 31)) return fail(c, FS_E_INVALID, "dense grids are limited to 2^32 cells (and 2^31 per z slice)");
@@ -988,7 +997,9 @@ int fs_upload_grid_bricks(fs_ctx *c, int32_t nx, int32_t ny, int32_t nz, const d
 {
     if (!c || !origin_xyz || n_bricks < 0 || (n_bricks > 0 && (!brick_xyz || !brick_cells))) return FS_E_INVALID;
     FS_HIP(c, hipSetDevice(c->device));
-    if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
+    if (nx <= 0 || ny <= 0 || nz <= 0 || !(resolution > 0.0) || !std::isfinite(resolution)) return fail(c, FS_E_INVALID, "bad grid shape or resolution");
+    // (worldToMap with a NaN origin is a float-to-integer conversion of NaN: undefined in the reference, refused here)
+    if (!std::isfinite(origin_xyz[0]) || !std::isfinite(origin_xyz[1]) || !std::isfinite(origin_xyz[2])) return fail(c, FS_E_INVALID, "grid origin must be finite");
     if ((nx & 7) || (ny & 7) || (nz & 7)) return fail(c, FS_E_INVALID, "brick upload needs dimensions that are multiples of 8");
     const uint64_t total = (uint64_t)nx * (uint64_t)ny * (uint64_t)nz;
     // (cell offsets are 32-bit unsigned in the walks, one z step is a signed 32-bit stride; everything else indexes in 64 bits)

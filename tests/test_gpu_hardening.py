@@ -309,3 +309,34 @@ def test_unusable_poses_spoil_only_themselves(fs, oracle, ref_table, angle):
             assert np.all((only["info_ref"][rest] == 0) | ~np.isfinite(only["info_ref"][rest])), only["info_ref"][rest]
     finally:
         s.close()
+
+
+def test_non_finite_parameters_are_refused(fs):
+    """NaN / infinite set-up values would turn worldToMap into a float-to-integer conversion of NaN (undefined in the reference) or a
+    ray fan of infinite length: refused with FS_E_INVALID, the context keeps what it had and goes on working."""
+    w = fs.synth.make_small_2d(3, n=96, n_cand=16, n_landmarks=300)
+    kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov, robot_radius=w.robot_radius,
+              n_rays=w.n_yaw, elev=w.elev, polygon=w.polygon)
+    s = fs.FrontierScorer(device=0)
+    try:
+        s.set_ray_params(**kw)
+        s.upload_grid(w.cells, w.origin, w.resolution)
+        s.upload_landmarks(w.landmarks); s.lookup_generate(); s.set_fim_params(14.0, 1.0)
+        s.max_arrival()
+        before = s.score_candidates(w.goals, w.frontier_size, w.blacklisted)
+        for origin, res in (((np.nan, 0.0, 0.0), 0.05), ((0.0, np.inf, 0.0), 0.05), ((0.0, 0.0, 0.0), np.inf), ((0.0, 0.0, 0.0), np.nan), ((0.0, 0.0, 0.0), 0.0), ((0.0, 0.0, 0.0), -0.05)):
+            with pytest.raises(fs.FsError):
+                s.upload_grid(w.cells, origin, res)
+        for bad in (dict(max_camera_depth=np.inf), dict(max_camera_depth=np.nan), dict(delta_theta=np.nan), dict(camera_fov=np.inf), dict(robot_radius=np.nan),
+                    dict(robot_radius=-0.1), dict(elev=(np.nan,)), dict(polygon=(np.nan, 0.0, 1.0, 1.0))):
+            with pytest.raises(fs.FsError):
+                s.set_ray_params(**dict(kw, **bad))
+        for dist, angle in ((np.nan, 1.0), (np.inf, 1.0), (1.0e9, 1.0), (0.0, 1.0), (14.0, np.nan), (14.0, 0.0)):
+            with pytest.raises(fs.FsError):
+                s.set_fim_params(dist, angle)
+        s.set_fim_params(9.9e8, 1.0); s.set_fim_params(14.0, 1.0)          # just inside the limit is fine
+        after = s.score_candidates(w.goals, w.frontier_size, w.blacklisted)
+        for k in ("arrival", "argmax", "n_visible", "flags"):
+            np.testing.assert_array_equal(after[k], before[k], err_msg=k)
+    finally:
+        s.close()
