@@ -256,6 +256,13 @@ def test_non_finite_and_far_away_landmarks_are_never_visible(fs, oracle, ref_tab
         assert np.max(np.abs(only["info_ref"] - want["info_f64"]) / sc) <= 1e-4
         assert np.max(np.abs(got["info_ref"] - base["info_ref"]) / sc) <= 1e-5
         assert want["n_visible"].min() > 100
+        # a cloud with no usable point at all
+        s.upload_landmarks(np.full((1000, 3), np.nan, dtype=np.float32))
+        for r in (s.score_fim(poses), s.score_fim(poses, info_only=True)):
+            assert not r["n_voxels"].any() and not r["info_ref"].any()
+        s.upload_landmarks(clean)
+        back = s.score_fim(poses)
+        np.testing.assert_array_equal(back["n_visible"], base["n_visible"])
     finally:
         s.close()
 
