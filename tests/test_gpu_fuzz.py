@@ -11,11 +11,14 @@ REL = 1e-4
 # by hand, for a wider sweep than the suite's 150 configurations: FS_FUZZ_SEEDS=3000 FS_FUZZ_BASE=100000 python -m pytest tests/test_gpu_fuzz.py -m gpu
 N_SEEDS = int(os.environ.get("FS_FUZZ_SEEDS", "150"))
 SEED_BASE = 9000 + int(os.environ.get("FS_FUZZ_BASE", "0"))
+TINY = bool(os.environ.get("FS_FUZZ_TINY"))      # every map a tiny one
 
 
 def _random_case(rng, fs):
     nx, ny = int(rng.integers(9, 90)), int(rng.integers(9, 90))
     nz = int(rng.choice([1, 1, 2, 5, 12]))
+    if TINY or rng.random() < 0.04:                                         # maps of a few cells (1 x 1 x 1 included)
+        nx, ny, nz = int(rng.integers(1, 9)), int(rng.integers(1, 9)), int(rng.choice([1, 1, 2, 3]))
     res = float(rng.choice([0.05, 0.1, 0.037]))
     origin = (float(rng.uniform(-3, 0.5)), float(rng.uniform(-3, 0.5)), float(rng.uniform(-0.5, 0.0)) if nz > 1 else 0.0)
     vals = np.array([0, 0, 0, 0, 255, 255, 255, 254, 253, 240, 100, 239], np.uint8)
