@@ -97,3 +97,32 @@ def test_robot_on_obstacle_off_map_and_hand_built_maps(fs, oracle, scorer):
         c3 = fs.synth.make_workload("C1", n_cand=4)
         scorer.upload_grid(c3.cells, c3.origin, c3.resolution)
         scorer.frontier_clusters((64, 64), (0.0, 0.0))
+
+
+import os
+
+N_RANDOM = int(os.environ.get("FS_CLUSTER_SEEDS", "40"))      # by hand: thousands
+
+
+@pytest.mark.parametrize("seed", range(N_RANDOM))
+def test_random_costmaps(fs, oracle, scorer, seed):
+    """Random byte maps (salt-and-pepper, so that components are many, small and oddly shaped; every cost value occurs), sizes from
+    1 x 1 up, random robot cells (free, lethal, unknown — the reference searches for the nearest free one), thresholds, distance
+    limits and cluster sizes: membership cell for cell, the cluster records and the reference's piece sizes."""
+    rng = np.random.default_rng(40_000 + seed + 1000 * int(os.environ.get("FS_CLUSTER_BASE", "0")))
+    nx, ny = (int(rng.integers(1, 10)), int(rng.integers(1, 10))) if rng.random() < 0.15 else (int(rng.integers(10, 140)), int(rng.integers(10, 140)))
+    res = float(rng.choice([0.05, 0.1, 0.25]))
+    origin = (float(rng.uniform(-5, 1)), float(rng.uniform(-5, 1)), 0.0)
+    p_unknown = float(rng.choice([0.2, 0.5, 0.8]))
+    vals = rng.choice(np.array([0, 0, 0, 1, 50, 159, 160, 200, 253, 254], np.uint8), size=(ny, nx))
+    cells = np.where(rng.random((ny, nx)) < p_unknown, np.uint8(255), vals).astype(np.uint8)
+    if rng.random() < 0.5:                                                  # blobs instead of salt and pepper
+        k = int(rng.integers(2, 9))
+        coarse = rng.random(((ny + k - 1) // k, (nx + k - 1) // k)) < p_unknown
+        cells = np.where(np.kron(coarse, np.ones((k, k), bool))[:ny, :nx], np.uint8(255), vals).astype(np.uint8)
+    scorer.upload_grid(cells[None], origin, res)
+    for _ in range(3):
+        x, y = int(rng.integers(0, nx)), int(rng.integers(0, ny))
+        pos = (origin[0] + (x + float(rng.uniform(0.05, 0.95))) * res, origin[1] + (y + float(rng.uniform(0.05, 0.95))) * res)
+        _check(fs, oracle, scorer, cells, origin, res, pos, lethal=int(rng.choice([1, 160, 250, 254])), max_cluster=int(rng.choice([1, 5, 20, 40])),
+               max_d=float(rng.choice([0.3, 1.5, 50.0])))
