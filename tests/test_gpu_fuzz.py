@@ -96,3 +96,42 @@ def test_random_configuration(fs, oracle, scorer, ref_table, seed):
         assert not rec["info_ref"][~ok].any() and not rec["n_visible"][~ok].any()
     finally:
         scorer.set_option("ray.layout", 0)
+
+
+N_SEG_SEEDS = int(os.environ.get("FS_SEGMENT_SEEDS", "60"))
+
+
+@pytest.mark.parametrize("seed", range(N_SEG_SEEDS))
+def test_random_segments(fs, oracle, scorer, seed):
+    """fs_trace_segments (the roadmap's isConnectable walk, DEP/src/planners/FrontierRoadmap.cpp:716-737; RayTracedCells with any
+    visitor ranges) on the random maps of this file: random end points — on the map, off it, in one cell, axis-aligned, along the
+    border —, random length limits and visitor ranges; every accessor (ok, cells traced, obstacle hit, unknown cells, all cells)
+    against the oracle's single-ray trace."""
+    rng = np.random.default_rng(SEED_BASE + 70_000 + seed)
+    k = _random_case(rng, fs)
+    G = oracle.Grid(k["cells"], origin=k["origin"], resolution=k["res"])
+    nz, ny, nx = k["cells"].shape
+    lo = np.array(k["origin"]); hi = lo + np.array([nx, ny, nz]) * k["res"]
+    n = int(rng.integers(1, 120))
+    a = rng.uniform(lo - 0.1, hi + 0.1, size=(n, 3)); b = rng.uniform(lo - 0.1, hi + 0.1, size=(n, 3))
+    inside = rng.random(n) < 0.8
+    a[inside] = np.clip(a[inside], lo + 1e-9, hi - 1e-9); b[inside] = np.clip(b[inside], lo + 1e-9, hi - 1e-9)
+    same = rng.random(n) < 0.1
+    b[same] = a[same]
+    axis = rng.random(n) < 0.2
+    b[axis, 1:] = a[axis, 1:]
+    if nz == 1:
+        a[:, 2] = b[:, 2] = k["origin"][2]
+    border = rng.random(n) < 0.1
+    a[border, 0] = lo[0]; b[border, 0] = hi[0] - 1e-9
+    obst = tuple(sorted(rng.integers(0, 262, size=2).tolist()))
+    trace = tuple(sorted(rng.integers(0, 262, size=2).tolist()))
+    max_len = float(rng.choice([1, 3, 17, 183, 1000]))
+    scorer.upload_grid(k["cells"], k["origin"], k["res"])
+    got = scorer.trace_segments(a, b, max_len, obst=obst, trace=trace)
+    for i in range(n):
+        r = oracle.trace_ray(G, tuple(a[i]), tuple(b[i]), max_len, obst=obst, trace=trace, faithful=True)
+        assert bool(got["ok"][i]) == r["ok"], (i, a[i], b[i])
+        if r["ok"]:
+            assert (got["traced"][i], bool(got["hit"][i]), got["unknown"][i], got["all"][i]) == (r["traced"], r["hit"], r["unknown"], r["all"]), \
+                (i, a[i], b[i], max_len, obst, trace)
