@@ -68,6 +68,12 @@ def test_get_frontier_costs_and_pose_safety(fs, oracle, ref_table, tmp_path, see
     p = subprocess.run([drv, str(wl), str(out)], capture_output=True, text=True, timeout=300)
     print(p.stdout, p.stderr)
     assert p.returncode == 0, p.stdout + p.stderr
+    if seed == 31:
+        # the same driver with the C++ mirror (frontier_scoring.hpp) under ASan + UBSan: no report, the same checks green
+        q = subprocess.run([hb.build(sanitize=True), str(wl), str(tmp_path / "r_san.bin")], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+        assert q.returncode == 0 and "ERROR: AddressSanitizer" not in q.stderr and "runtime error" not in q.stderr and "failures: 0" in q.stdout, \
+            q.stdout[-1500:] + q.stderr[-3000:]
     assert "DID NOT THROW" not in p.stdout and "failures: 0" in p.stdout
     raw = np.fromfile(out, dtype=np.float64)
     n_c = w.goals.shape[0]
