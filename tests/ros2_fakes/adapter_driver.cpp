@@ -38,7 +38,7 @@ static bool throws(F fn, const char *what)
 
 int main(int argc, char **argv)
 {
-    if (argc < 4) { fprintf(stderr, "usage: %s workload.bin lookup_table.dat result.bin\n", argv[0]); return 2; }
+    if (argc < 4) { fprintf(stderr, "usage: %s workload.bin lookup_table.dat result.bin [regenerate]\n", argv[0]); return 2; }
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     int32_t nx, ny, n, m;
@@ -143,6 +143,14 @@ int main(int argc, char **argv)
         pose0.orientation = nav2_util::geometry_utils::orientationAroundZAxis(yaw_of[0]);
         float info = -1.0f;
         EXPECT(!fim.isPoseSafe(pose0, false, info), "isPoseSafe before any map_data -> false");
+        if (argc > 4 && std::string(argv[4]) == "regenerate") {
+            // generateLookupTable with gen_fi_lookup's bounds (DEP/src/fisher_information/GenerateLookupMain.cpp:9): rewrites the file the
+            // node parameter names — the test compares its bytes with the oracle's records — and reads it back
+            const float h = (float)(8.5 * 1.732);                 // (double literals narrowed at the call, as GenerateLookupMain.cpp:9 has them)
+            fim.generateLookupTable(0.0f, 21.0f, -h, h, -h, h);
+            fim.loadLookupTable();
+            printf("check ok: generateLookupTable + loadLookupTable through the manager\n");
+        }
         // the SLAM front end publishes the map: every landmark twice (two key-frames see it), a NaN point, over two nodes
         auto msg = std::make_shared<slam_msgs::msg::MapData>();
         msg->nodes.resize(2);

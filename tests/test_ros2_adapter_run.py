@@ -121,9 +121,18 @@ def test_adapter_runs_on_the_gpu_and_matches_the_oracle(fs, oracle, ref_table, s
     scorer.lookup_generate()
     scorer.lookup_save(str(table))
     out = tmp_path / "r.bin"
-    p = subprocess.run([exe, str(wl), str(table), str(out)], capture_output=True, text=True, timeout=300)
+    # (seed 77: the manager also REGENERATES the table file — a deliberately wrong file is put there first — and loads it back)
+    regenerate = seed == 77
+    if regenerate:
+        scorer.lookup_generate((0.0, 3.0, -2.0, 2.0, -1.0, 1.0))
+        scorer.lookup_save(str(table))
+        scorer.lookup_generate()
+    p = subprocess.run([exe, str(wl), str(table), str(out)] + (["regenerate"] if regenerate else []), capture_output=True, text=True, timeout=300)
     print(p.stdout, p.stderr)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    if regenerate:
+        assert "check ok: generateLookupTable + loadLookupTable through the manager" in p.stdout
+        assert open(table, "rb").read() == ref_table.records.tobytes()          # the file gen_fi_lookup would write, byte for byte
     if seed == 31:
         # the same run with the adapter, the doubles and the driver under ASan + UBSan: no report, the same bytes out
         exe_san = build_driver(tmp_path, sanitize=True)
