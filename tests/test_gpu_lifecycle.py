@@ -209,8 +209,8 @@ def _poison_library(env, root):
 def test_two_contexts_from_two_threads_at_once(fs):
     """The ROS adapter holds two scorer objects — CostAssignerGPU on the behaviour-tree thread, FisherInformationManagerGPU behind its
     own mutex — so two host threads may be inside the library at the same time, each on a context of its own (a context itself is
-    single-caller: include/fitslam_frontier.h).  Two threads (ctypes releases the interpreter lock during a call), one context each,
-    a few hundred mixed small calls each, at once: every result must be the one a single thread gets."""
+    single-caller: include/fitslam_frontier.h).  Three threads (ctypes releases the interpreter lock during a call) — two with a context each, one with a two-member
+    multi-device scorer —, a few hundred mixed small calls each, at once: every result must be the one a single thread gets."""
     import threading
     w = fs.synth.make_workload("REF2D", n_cand=300)
     ctx, limits = _make(fs, w)
@@ -235,9 +235,16 @@ def test_two_contexts_from_two_threads_at_once(fs):
             except BaseException as e:                       # noqa: BLE001  (reported by the main thread)
                 errors.append(e)
 
+        # ... and a third thread on a two-member multi-device scorer (its own two contexts and streams on the same GPU; the kinds it has)
+        multi = fs.MultiScorer(devices=(0, 0))
+        multi.set_ray_params(**_params(w)); multi.upload_grid(w.cells, w.origin, w.resolution)
+        multi.upload_landmarks(w.landmarks); multi.lookup_generate(); multi.set_arrival_limits(limits["max_gt"], limits["min_gt"])
+        multi_order = [i for i in range(len(plan)) if plan[i][0] != "arrival"][::2]
         a = threading.Thread(target=run, args=(ctx, list(range(len(plan)))))
         b = threading.Thread(target=run, args=(other, list(reversed(range(len(plan))))))
-        a.start(); b.start(); a.join(); b.join()
+        c = threading.Thread(target=run, args=(multi, multi_order))
+        a.start(); b.start(); c.start(); a.join(); b.join(); c.join()
+        multi.close()
         assert not errors, errors[0]
     finally:
         ctx.close(); other.close()
