@@ -26,7 +26,7 @@
 #include <thread>
 #include <vector>
 
-enum { FS_GATHER_AUTO = 0, FS_GATHER_PEER = 1, FS_GATHER_HOST = 2, FS_GATHER_COPY = 3 };
+enum { FS_GATHER_AUTO = 0, FS_GATHER_PEER = 1, FS_GATHER_HOST = 2, FS_GATHER_COPY = 3, FS_GATHER_PEER_CALL = 4 };
 
 struct fs_multi {
     std::vector<fs_ctx *> ctx;
@@ -192,9 +192,9 @@ const char *fs_multi_last_error(const fs_multi *m) { return m ? m->err.c_str() :
 
 int fs_multi_set_option(fs_multi *m, const char *key, double value)
 {
-    if (m && key && std::string(key) == "multi.gather") {      // 0 auto | 1 peer copies | 2 host bounce | 3 device copies also between members of one GPU
+    if (m && key && std::string(key) == "multi.gather") {      // 0 auto | 1 peer copies | 2 host bounce | 3 device copies also between members of one GPU | 4 the same through hipMemcpyPeerAsync
         const int v = (int)value;
-        if (v < FS_GATHER_AUTO || v > FS_GATHER_COPY) return multi_fail(m, FS_E_INVALID, "multi.gather takes 0 (auto), 1 (peer), 2 (host bounce) or 3 (copy)");
+        if (v < FS_GATHER_AUTO || v > FS_GATHER_PEER_CALL) return multi_fail(m, FS_E_INVALID, "multi.gather takes 0 (auto), 1 (peer), 2 (host bounce), 3 (copy) or 4 (peer-copy call)");
         m->gather_forced = v;
         if (v == FS_GATHER_HOST) m->err = "multi.gather = 2: record blocks bounce through page-locked host memory";
         return FS_OK;
@@ -408,7 +408,8 @@ int fs_multi_get_frontier_costs(fs_multi *m, int32_t n, const double *goal_xyz, 
             if (mode == FS_GATHER_HOST) {
                 rc = fs_block_records_to_host(cg, cnt, d_block, &h_block);
                 if (rc != FS_OK) { first_error = multi_fail(m, rc, "block %d to host (device %d): %s", g, dev, fs_last_error(cg)); break; }
-            } else if (dev != dev0) {
+            } else if (dev != dev0 || mode == FS_GATHER_PEER_CALL) {
+                // (mode 4: the peer-copy CALL also between two members of one GPU — the only way a one-GPU box executes this line)
                 e = hipMemcpyPeerAsync(d_list + l, dev0, d_block, dev, bytes, sg);        // over xGMI, behind the block's kernels
             } else {
                 e = hipMemcpyAsync(d_list + l, d_block, bytes, hipMemcpyDeviceToDevice, sg);

@@ -336,7 +336,8 @@ int  fs_multi_get_frontier_costs(fs_multi *m, int32_t n, const double *goal_xyz,
                                  fs_record *records, double *weighted_cost, double *arrival_utility, double *distance_utility, int32_t *order);
 /* how fs_multi_get_frontier_costs moves the blocks: 1 device to device (peer access granted, or every member on one GPU),
    2 through page-locked host memory (peer access refused), 3 / forced values: fs_multi_set_option("multi.gather", 0 auto | 1 | 2 | 3
-   = device copies even between members of one GPU), for tests of the paths a one-GPU box cannot take by itself.  < 0: error */
+   = device copies even between members of one GPU | 4 = those copies through hipMemcpyPeerAsync), for tests of the paths a one-GPU
+   box cannot take by itself.  < 0: error */
 int  fs_multi_gather_mode(fs_multi *m);
 
 /* ---------------------------------------------------------------- utility + ranking */

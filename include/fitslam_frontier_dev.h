@@ -63,7 +63,8 @@ int  fs_set_option(fs_ctx *ctx, const char *key, double value);
  * 6 = unresolved (always 0), 12 / 13 = the largest voxels-per-landmark ratio (in 1/256) a big candidate of the finished calls
  * showed (the pass prediction's input; reset with the cloud, the table and the visibility volume) — 12 per landmark of the
  * chunks in range and cone (the cone workers), 13 per landmark of the chunks that can also meet the lookup table's box (the
- * cone-off and info-only workers).  Host-side: 1000 / 1001 = bricks of the grid / bricks in the pool of "ray.layout" 3. */
+ * cone-off and info-only workers); 10 / 11 = landmark tests / candidates since the last spatially sorted call (the sort's own
+ * accumulators: CLEARED by every call of 2048 candidates or more — not running totals).  Host-side: 1000 / 1001 = bricks of the grid / bricks in the pool of "ray.layout" 3. */
 int  fs_get_counter(fs_ctx *ctx, int which, int64_t *value, int reset);
 
 /* ---------------------------------------------------------------- self test */

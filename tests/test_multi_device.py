@@ -113,12 +113,13 @@ def _path_columns(n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("with_fim", [False, True])
 @pytest.mark.parametrize("devices,n_cand,gather", [((0, 0), 5000, 0), ((0, 0, 0), 4999, 0), ((0, 0), 3000, 3), ((0, 0, 0), 2500, 2),
-                                                   ((0, 0, 0, 0), 3, 3), ((0,), 300, 0), ((0, 0), 700, 2)])
+                                                   ((0, 0, 0, 0), 3, 3), ((0,), 300, 0), ((0, 0), 700, 2), ((0, 0, 0), 2600, 4), ((0, 0), 40, 4)])
 def test_multi_get_frontier_costs_equals_one_context(fs, devices, n_cand, gather, with_fim):
     """CostAssigner::getFrontierCosts as ONE call over several members (VERDICT r04 missing #2): the records stay on the devices
     between scoring and ranking.  `gather`: 0 = what set-up chose (members of one GPU write the gathered list in place),
     3 = every other member's block is a device copy on its own stream + an event member 0's stream waits for (the machinery a
-    second physical GPU uses with hipMemcpyPeerAsync), 2 = the fallback where peer access is refused: blocks bounce through
+    second physical GPU uses with hipMemcpyPeerAsync), 4 = the same with the hipMemcpyPeerAsync CALL itself (source and destination
+    device the same: the one way a one-GPU box executes that line), 2 = the fallback where peer access is refused: blocks bounce through
     page-locked host memory.  All must give the one-context call's results: integers, costs, utilities and order bit for bit."""
     w = fs.synth.make_workload("C2", n_cand=n_cand)
     kw = dict(max_camera_depth=w.max_camera_depth, delta_theta=w.delta_theta, camera_fov=w.camera_fov,
