@@ -39,6 +39,10 @@ if os.environ.get("FS_HOST_ASAN"):        # AddressSanitizer on the HOST side of
     DEV_FLAGS += ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-g"]   # run with LD_PRELOAD=<clang's libclang_rt.asan-x86_64.so>
     LINK_FLAGS = ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"]
     RESOURCE_LIMITS = {}
+if os.environ.get("FS_HOST_COV"):         # gcov-format line coverage of the HOST side (clang's --coverage for the host compile only; read with gcov-11)
+    DEV_FLAGS += ["-Xarch_host", "-fprofile-arcs", "-Xarch_host", "-ftest-coverage"]
+    LINK_FLAGS = LINK_FLAGS + ["--coverage"]
+    RESOURCE_LIMITS = {}
 if os.environ.get("FS_T1_WAVES_PER_EU"):  # occupancy target of the FIM worker's register allocation
     DEV_FLAGS.append("-DFS_T1_WAVES_PER_EU=" + os.environ["FS_T1_WAVES_PER_EU"])
     RESOURCE_LIMITS = {}
