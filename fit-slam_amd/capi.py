@@ -21,14 +21,14 @@ FS_MAX_ELEV = 16
 EXPORTED_SYMBOLS = [
     "fs_abi_version", "fs_ctx_create", "fs_ctx_destroy", "fs_last_error", "fs_synchronize",
     "fs_enable_kernel_timing", "fs_kernel_time", "fs_set_option", "fs_get_counter",
-    "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_upload_grid_bricks", "fs_frontier_cells", "fs_frontier_clusters", "fs_max_arrival", "fs_set_arrival_limits",
+    "fs_set_ray_params", "fs_ray_fan_shape", "fs_upload_grid", "fs_upload_grid_bricks", "fs_update_grid_region", "fs_frontier_cells", "fs_frontier_clusters", "fs_max_arrival", "fs_set_arrival_limits",
     "fs_score_arrival", "fs_trace_segments",
     "fs_upload_landmarks", "fs_lookup_generate", "fs_lookup_load", "fs_lookup_save", "fs_lookup_set_records",
     "fs_lookup_num_records", "fs_lookup_get_records", "fs_lookup_query", "fs_set_fim_params", "fs_score_fim", "fs_information_frontier_pair",
     "fs_upload_keyframes", "fs_information_for_pose",
     "fs_score_candidates", "fs_score_candidates_dev", "fs_rank_candidates", "fs_rank_candidates_dev", "fs_get_frontier_costs", "fs_selftest_fp64",
     "fs_multi_create", "fs_multi_destroy", "fs_multi_num_devices", "fs_multi_ctx", "fs_multi_last_error", "fs_multi_shard_bounds",
-    "fs_multi_set_option", "fs_multi_set_ray_params", "fs_multi_upload_grid", "fs_multi_upload_landmarks", "fs_multi_lookup_generate",
+    "fs_multi_set_option", "fs_multi_set_ray_params", "fs_multi_upload_grid", "fs_multi_update_grid_region", "fs_multi_upload_landmarks", "fs_multi_lookup_generate",
     "fs_multi_lookup_load", "fs_multi_set_fim_params", "fs_multi_max_arrival", "fs_multi_score_arrival", "fs_multi_score_candidates",
     "fs_multi_score_fim", "fs_multi_get_frontier_costs", "fs_multi_gather_mode",
 ]
@@ -101,6 +101,8 @@ def load_library(build: bool = True):
     L.fs_ray_fan_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.fs_upload_grid.argtypes = [vp, vp, i32, i32, i32, C.POINTER(dbl * 3), dbl]
     L.fs_upload_grid_bricks.argtypes = [vp, i32, i32, i32, C.POINTER(dbl * 3), dbl, C.c_uint8, i64, vp, vp]
+    L.fs_update_grid_region.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i64, i64]
+    L.fs_multi_update_grid_region.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, i64, i64]
     L.fs_frontier_cells.argtypes = [vp, i32, vp, C.POINTER(i64)]
     L.fs_frontier_clusters.argtypes = [vp, C.POINTER(dbl * 2), i32, dbl, i32, vp, i32, vp, C.POINTER(i32), C.POINTER(i64)]
     L.fs_max_arrival.argtypes = [vp, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(dbl)]
@@ -158,6 +160,22 @@ def load_library(build: bool = True):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _window_args(window, view):
+    """(pointer, sx, sy, sz, row_stride, slice_stride, keep-alive) of a window given as its own array [sz][sy][sx] (or [sy][sx]),
+    or — view=True — as a numpy VIEW into the caller's whole map: the view's strides are passed on and nothing is packed"""
+    w = np.asarray(window, dtype=np.uint8)
+    if w.ndim == 2:
+        w = w[None]
+    if not view or w.size == 0:
+        w = np.ascontiguousarray(w)
+        sz, sy, sx = w.shape
+        return _p(w), sx, sy, sz, 0, 0, w
+    if w.strides[2] != 1:
+        raise ValueError("a window view must be contiguous along x")
+    sz, sy, sx = w.shape
+    return C.c_void_p(w.ctypes.data), sx, sy, sz, (w.strides[1] if sy > 1 else 0), (w.strides[0] if sz > 1 else 0), w
 
 
 class FrontierScorer:
@@ -232,6 +250,12 @@ class FrontierScorer:
         nz, ny, nx = c.shape
         o = (C.c_double * 3)(*[float(v) for v in origin])
         self._check(self._L.fs_upload_grid(self._h, _p(c), nx, ny, nz, C.byref(o), float(resolution)))
+
+    def update_grid_region(self, x0, y0, z0, window, view=False):
+        """fs_update_grid_region: `window` [sz][sy][sx] (or [sy][sx]) replaces the cells from (x0, y0, z0) on; view=True passes a
+        numpy view into the caller's whole map with its strides (nothing packed on the Python side)"""
+        ptr, sx, sy, sz, rs, ss, keep = _window_args(window, view)
+        self._check(self._L.fs_update_grid_region(self._h, int(x0), int(y0), int(z0), sx, sy, sz, ptr, rs, ss))
 
     def upload_grid_bricks(self, shape_zyx, origin, resolution, brick_xyz, brick_cells, default_value=255):
         nz, ny, nx = shape_zyx
@@ -498,6 +522,10 @@ class MultiScorer:
         nz, ny, nx = c.shape
         o = (C.c_double * 3)(*[float(v) for v in origin])
         self._check(self._L.fs_multi_upload_grid(self._h, _p(c), nx, ny, nz, C.byref(o), float(resolution)))
+
+    def update_grid_region(self, x0, y0, z0, window, view=False):
+        ptr, sx, sy, sz, rs, ss, keep = _window_args(window, view)
+        self._check(self._L.fs_multi_update_grid_region(self._h, int(x0), int(y0), int(z0), sx, sy, sz, ptr, rs, ss))
 
     def upload_landmarks(self, xyz):
         lm = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)

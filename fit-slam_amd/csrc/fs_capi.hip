@@ -248,7 +248,8 @@ struct fs_ctx {
     // scratch of the per-tick entry points (fs_trace_segments, fs_frontier_cells, fs_information_frontier_pair,
     // fs_upload_grid_bricks): owned by the context and grown on demand, never allocated and freed per call
     DevBuf<double> d_seg_start, d_seg_end, d_tri;
-    DevBuf<uint8_t> d_seg_ok, d_seg_hit, d_mask, d_brick_cells;
+    DevBuf<uint8_t> d_seg_ok, d_seg_hit, d_mask, d_brick_cells, d_win;
+    PinnedBuf h_win;               // fs_update_grid_region: the packed window
     DevBuf<int32_t> d_seg_traced, d_seg_unknown, d_seg_all, d_brick_xyz, d_bad;
     DevBuf<unsigned long long> d_count;
     // fs_frontier_clusters
@@ -831,7 +832,7 @@ void fs_ctx_destroy(fs_ctx *c)
     c->d_overflow.release(); c->d_tested.release(); c->d_split_flags.release(); c->d_flagged.release(); c->d_records.release();
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->sort_scratch) (void)hipFree(c->sort_scratch);
-    c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release(); c->h_fin.release();
+    c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release(); c->h_fin.release(); c->h_win.release(); c->d_win.release();
     c->d_seg_start.release(); c->d_seg_end.release(); c->d_tri.release(); c->d_seg_ok.release(); c->d_seg_hit.release();
     c->d_mask.release(); c->d_brick_cells.release(); c->d_seg_traced.release(); c->d_seg_unknown.release();
     c->d_seg_all.release(); c->d_brick_xyz.release(); c->d_bad.release(); c->d_count.release();
@@ -988,6 +989,44 @@ int fs_upload_grid(fs_ctx *c, const uint8_t *cells, int32_t nx, int32_t ny, int3
     c->res = resolution;
     c->have_grid = true;
     c->max_gt = 0.0; c->min_gt = 0.0;
+    ++c->epoch;
+    return FS_OK;
+}
+
+// Layer::updateCosts' window of the master grid (include/fitslam_frontier.h): packed on the host into page-locked memory, one
+// transfer, one scatter into the row-major image, and the class image re-cut for the bricks the window touches (a whole-map
+// re-cut is a streaming pass over the grid — 1 GiB on C5 — for a window of a few thousand cells).
+int fs_update_grid_region(fs_ctx *c, int32_t x0, int32_t y0, int32_t z0, int32_t sx, int32_t sy, int32_t sz,
+                          const uint8_t *cells, int64_t row_stride, int64_t slice_stride)
+{
+    if (!c) return FS_E_INVALID;
+    FS_HIP(c, hipSetDevice(c->device));
+    if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
+    if (sx < 0 || sy < 0 || sz < 0) return fail(c, FS_E_INVALID, "negative window size");
+    if (x0 < 0 || y0 < 0 || z0 < 0 || (int64_t)x0 + sx > c->nx || (int64_t)y0 + sy > c->ny || (int64_t)z0 + sz > c->nz)
+        return fail(c, FS_E_INVALID, "window [%d,%d) x [%d,%d) x [%d,%d) leaves the %d x %d x %d grid", x0, x0 + sx, y0, y0 + sy, z0, z0 + sz, c->nx, c->ny, c->nz);
+    if (sx == 0 || sy == 0 || sz == 0) return FS_OK;
+    if (!cells) return FS_E_INVALID;
+    if (row_stride == 0) row_stride = sx;
+    if (slice_stride == 0) slice_stride = row_stride * (int64_t)sy;
+    if (row_stride < sx || slice_stride < row_stride * (int64_t)(sy - 1) + sx) return fail(c, FS_E_INVALID, "window strides smaller than the window");
+    const size_t total = (size_t)sx * (size_t)sy * (size_t)sz;
+    FS_HIP(c, c->h_win.ensure(total));
+    FS_HIP(c, c->d_win.ensure(total));
+    for (int32_t z = 0; z < sz; ++z)
+        for (int32_t y = 0; y < sy; ++y)
+            std::memcpy(c->h_win.p + ((size_t)z * sy + y) * sx, cells + (size_t)z * (size_t)slice_stride + (size_t)y * (size_t)row_stride, (size_t)sx);
+    FS_HIP(c, hipMemcpyAsync(c->d_win.p, c->h_win.p, total, hipMemcpyHostToDevice, c->stream));
+    FS_HIP(c, fs_launch_window_scatter(c->d_win.p, c->d_cells.p, c->nx, c->ny, x0, y0, z0, sx, sy, sz, c->stream));
+    if (c->have_cls) {
+        const int b0[3] = {x0 >> 3, y0 >> 3, z0 >> 3};
+        const int nb[3] = {((x0 + sx - 1) >> 3) - b0[0] + 1, ((y0 + sy - 1) >> 3) - b0[1] + 1, ((z0 + sz - 1) >> 3) - b0[2] + 1};
+        FS_HIP(c, fs_launch_classify_region(c->d_cells.p, c->d_cls.p, c->nx, c->ny, c->nz, c->cls_ranges[0], c->cls_ranges[1], c->cls_ranges[2],
+                                            c->cls_ranges[3], b0, nb, c->stream));
+    }
+    c->have_sparse = false;
+    FS_HIP(c, hipStreamSynchronize(c->stream));                  // (the page-locked window is the next call's again)
+    if (c->h_win.cap > ((size_t)64 << 20)) { c->h_win.release(); c->d_win.release(); }   // (a window of map size: not worth keeping)
     ++c->epoch;
     return FS_OK;
 }

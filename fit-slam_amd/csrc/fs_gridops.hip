@@ -112,16 +112,19 @@ void fs_frontier_pair_kernel(int n, const float *lx, const float *ly, const floa
 }
 
 // dense row-major grid -> 2-bit class image in 8 x 8 x 8 bricks (fs_internal.h, FsGridDev::cls): one thread classifies the 16
-// cells of one dword — two x-rows of a brick — from the row-major image
+// cells of one dword — two x-rows of a brick — from the row-major image.  The launch covers the sub-box of sub.n bricks that
+// starts at brick sub.b0 (the whole image, or the bricks a rewritten window of the map touches: fs_update_grid_region)
+struct BrickBox { uint32_t b0[3], n[3]; };
 __global__ void fs_classify_kernel(const uint8_t *__restrict__ cells, uint32_t *__restrict__ cls, int nx, int ny, int nz,
-                                   int omin, int omax, int tmin, int tmax)
+                                   int omin, int omax, int tmin, int tmax, BrickBox sub)
 {
-    const uint32_t bx = (uint32_t)(nx + 7) >> 3, by = (uint32_t)(ny + 7) >> 3, bz = (uint32_t)(nz + 7) >> 3;
-    const long long total = (long long)bx * by * bz * 32;
+    const uint32_t bx = (uint32_t)(nx + 7) >> 3, by = (uint32_t)(ny + 7) >> 3;
+    const long long total = (long long)sub.n[0] * sub.n[1] * sub.n[2] * 32;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const uint32_t d = (uint32_t)(i & 31);                    // dword of the brick: (z & 7) * 4 + (y & 7) / 2
         const long long brick = i >> 5;
-        const uint32_t ix = (uint32_t)(brick % bx), iy = (uint32_t)((brick / bx) % by), iz = (uint32_t)(brick / ((long long)bx * by));
+        const uint32_t ix = sub.b0[0] + (uint32_t)(brick % sub.n[0]), iy = sub.b0[1] + (uint32_t)((brick / sub.n[0]) % sub.n[1]),
+                       iz = sub.b0[2] + (uint32_t)(brick / ((long long)sub.n[0] * sub.n[1]));
         const int x0 = (int)(ix << 3), y0 = (int)((iy << 3) | ((d & 3u) << 1)), z = (int)((iz << 3) | (d >> 2));
         uint32_t word = 0u;
         if (z < nz) {
@@ -133,7 +136,17 @@ __global__ void fs_classify_kernel(const uint8_t *__restrict__ cells, uint32_t *
                 word |= code << (2 * k);
             }
         }
-        cls[i] = word;
+        cls[((((size_t)iz * by + iy) * bx + ix) << 5) | d] = word;
+    }
+}
+
+// a rewritten window of the map, packed [sz][sy][sx], into the row-major image at (x0, y0, z0): one thread per cell, x fastest
+__global__ void fs_window_scatter_kernel(const uint8_t *__restrict__ win, uint8_t *__restrict__ grid, int nx, int ny,
+                                         int x0, int y0, int z0, int sx, int sy, long long total)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % sx), y = (int)((i / sx) % sy), z = (int)(i / ((long long)sx * sy));
+        grid[((size_t)(z0 + z) * ny + (size_t)(y0 + y)) * nx + (size_t)(x0 + x)] = win[i];
     }
 }
 
@@ -144,12 +157,31 @@ size_t fs_class_image_words(int nx, int ny, int nz)
     return (size_t)((nx + 7) >> 3) * (size_t)((ny + 7) >> 3) * (size_t)((nz + 7) >> 3) * 32;
 }
 
+hipError_t fs_launch_classify_region(const uint8_t *d_cells, uint32_t *d_cls, int nx, int ny, int nz, int obst_min, int obst_max,
+                                     int trace_min, int trace_max, const int brick0[3], const int n_bricks[3], hipStream_t s)
+{
+    const BrickBox sub{{(uint32_t)brick0[0], (uint32_t)brick0[1], (uint32_t)brick0[2]}, {(uint32_t)n_bricks[0], (uint32_t)n_bricks[1], (uint32_t)n_bricks[2]}};
+    const size_t words = (size_t)n_bricks[0] * (size_t)n_bricks[1] * (size_t)n_bricks[2] * 32;
+    if (words == 0) return hipSuccess;
+    const int blocks = (int)std::min<size_t>((words + 255) / 256, 65535u * 16u);
+    hipLaunchKernelGGL(fs_classify_kernel, dim3(blocks), dim3(256), 0, s, d_cells, d_cls, nx, ny, nz, obst_min, obst_max, trace_min, trace_max, sub);
+    return hipGetLastError();
+}
+
 hipError_t fs_launch_classify(const uint8_t *d_cells, uint32_t *d_cls, int nx, int ny, int nz, int obst_min, int obst_max,
                               int trace_min, int trace_max, hipStream_t s)
 {
-    const size_t words = fs_class_image_words(nx, ny, nz);
-    const int blocks = (int)std::min<size_t>((words + 255) / 256, 65535u * 16u);
-    hipLaunchKernelGGL(fs_classify_kernel, dim3(blocks), dim3(256), 0, s, d_cells, d_cls, nx, ny, nz, obst_min, obst_max, trace_min, trace_max);
+    const int b0[3] = {0, 0, 0}, nb[3] = {(nx + 7) >> 3, (ny + 7) >> 3, (nz + 7) >> 3};
+    return fs_launch_classify_region(d_cells, d_cls, nx, ny, nz, obst_min, obst_max, trace_min, trace_max, b0, nb, s);
+}
+
+hipError_t fs_launch_window_scatter(const uint8_t *d_window, uint8_t *d_grid, int nx, int ny, int x0, int y0, int z0,
+                                    int sx, int sy, int sz, hipStream_t s)
+{
+    const long long total = (long long)sx * sy * sz;
+    if (total <= 0) return hipSuccess;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 65535ll * 16);
+    hipLaunchKernelGGL(fs_window_scatter_kernel, dim3(blocks), dim3(256), 0, s, d_window, d_grid, nx, ny, x0, y0, z0, sx, sy, total);
     return hipGetLastError();
 }
 

@@ -48,6 +48,12 @@ struct FsGridDev {
 size_t fs_class_image_words(int nx, int ny, int nz);
 hipError_t fs_launch_classify(const uint8_t *d_cells, uint32_t *d_cls, int nx, int ny, int nz, int obst_min, int obst_max,
                               int trace_min, int trace_max, hipStream_t s);
+// ... only the n_bricks[3] bricks from brick brick0[3] on (what a rewritten window of the map touches), and the kernel that puts
+// a packed window [sz][sy][sx] into the row-major image at (x0, y0, z0): fs_update_grid_region
+hipError_t fs_launch_classify_region(const uint8_t *d_cells, uint32_t *d_cls, int nx, int ny, int nz, int obst_min, int obst_max,
+                                     int trace_min, int trace_max, const int brick0[3], const int n_bricks[3], hipStream_t s);
+hipError_t fs_launch_window_scatter(const uint8_t *d_window, uint8_t *d_grid, int nx, int ny, int x0, int y0, int z0,
+                                    int sx, int sy, int sz, hipStream_t s);
 
 struct FsRayArgs {
     FsGridDev grid;

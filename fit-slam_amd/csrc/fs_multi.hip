@@ -212,6 +212,12 @@ int fs_multi_upload_grid(fs_multi *m, const uint8_t *cells, int32_t nx, int32_t 
     return for_all_parallel(m, "fs_upload_grid", [&](fs_ctx *c) { return fs_upload_grid(c, cells, nx, ny, nz, origin_xyz, resolution); });
 }
 
+int fs_multi_update_grid_region(fs_multi *m, int32_t x0, int32_t y0, int32_t z0, int32_t sx, int32_t sy, int32_t sz,
+                                const uint8_t *cells, int64_t row_stride, int64_t slice_stride)
+{
+    return for_all_parallel(m, "fs_update_grid_region", [&](fs_ctx *c) { return fs_update_grid_region(c, x0, y0, z0, sx, sy, sz, cells, row_stride, slice_stride); });
+}
+
 int fs_multi_upload_landmarks(fs_multi *m, const float *xyz, int32_t n_landmarks)
 {
     if (!m || (n_landmarks > 0 && !xyz) || n_landmarks < 0) return FS_E_INVALID;

@@ -217,6 +217,18 @@ public:
         if (arrival_info_limits_set_) ctx_->check(fs_set_arrival_limits(ctx_->get(), max_arrival_info_gt_, min_arrival_info_gt_), "fs_set_arrival_limits");
     }
 
+    // The window [min_i, max_i) x [min_j, max_j) a costmap update cycle rewrote (the bounds every layer's updateCosts is called
+    // with, DEP/src/nav2_plugins/lethal_marker.cpp:305-306): sent straight from the live character map, strides passed on.
+    // The map must still have the staged shape, origin and resolution — otherwise take a new snapshot (updateCostmap).
+    void updateCostmapWindow(int min_i, int min_j, int max_i, int max_j)
+    {
+        std::lock_guard<std::mutex> lock(exploration_costmap_->getMutex());
+        const int64_t size_x = (int64_t)exploration_costmap_->getSizeInCellsX(), size_y = (int64_t)exploration_costmap_->getSizeInCellsY();
+        ctx_->check(fs_update_grid_region(ctx_->get(), min_i, min_j, 0, max_i - min_i, max_j - min_j, (int32_t)exploration_costmap_->getSizeInCellsZ(),
+                                          exploration_costmap_->getCharMap() + (int64_t)min_j * size_x + min_i, size_x, size_x * size_y),
+                    "fs_update_grid_region");
+    }
+
     // DEP/src/CostCalculator.cpp:23-121 for one frontier.
     void setArrivalInformationForFrontier(FrontierPtr &frontier, std::vector<double> &polygon_xy_min_max)
     {
@@ -803,6 +815,14 @@ public:
         const double origin[3] = {costmap.getOriginX(), costmap.getOriginY(), costmap.getOriginZ()};
         check(fs_multi_upload_grid(m_, costmap.getCharMap(), (int32_t)costmap.getSizeInCellsX(), (int32_t)costmap.getSizeInCellsY(),
                                    (int32_t)costmap.getSizeInCellsZ(), origin, costmap.getResolution()), "fs_multi_upload_grid");
+    }
+    // ... and the window a costmap update cycle rewrote, on every device (fs_multi_update_grid_region)
+    void updateCostmapWindow(Costmap2D &costmap, int min_i, int min_j, int max_i, int max_j)
+    {
+        std::lock_guard<std::mutex> lock(costmap.getMutex());
+        const int64_t size_x = (int64_t)costmap.getSizeInCellsX(), size_y = (int64_t)costmap.getSizeInCellsY();
+        check(fs_multi_update_grid_region(m_, min_i, min_j, 0, max_i - min_i, max_j - min_j, (int32_t)costmap.getSizeInCellsZ(),
+                                          costmap.getCharMap() + (int64_t)min_j * size_x + min_i, size_x, size_x * size_y), "fs_multi_update_grid_region");
     }
     void setLandmarks(const std::vector<float> &xyz) { check(fs_multi_upload_landmarks(m_, xyz.data(), (int32_t)(xyz.size() / 3)), "fs_multi_upload_landmarks"); }
     void generateLookupTable() { check(fs_multi_lookup_generate(m_, nullptr), "fs_multi_lookup_generate"); }

@@ -272,6 +272,62 @@ int main(int argc, char **argv)
         if (bad3) ++failures;
     }
 
+    // A costmap update cycle between two ticks: a layer rewrites a window of the master grid (Layer::updateCosts' bounds) and only that
+    // window is sent (FrontierCostCalculator::updateCostmapWindow -> fs_update_grid_region; ShardedScorer likewise, on every device).
+    // Arrival information, yaw and achievability must equal those of a calculator that snapshots the whole rewritten map.
+    {
+        std::vector<double> poly_v(poly, poly + 4);
+        auto fresh_list = [&]() {
+            std::vector<FrontierPtr> v;
+            for (int32_t i = 0; i < n; ++i) {
+                auto fr = std::make_shared<Frontier>();
+                fr->setUID((size_t)i + 1); fr->setSize(sizes[i]); fr->setGoalPoint(goals[2 * i], goals[2 * i + 1]); fr->setAchievability(true);
+                v.push_back(fr);
+            }
+            return v;
+        };
+        const std::vector<uint8_t> saved(costmap->getCharMap(), costmap->getCharMap() + (size_t)nx * ny);
+        FrontierCostCalculator windowed(std::make_shared<ScoringContext>(0), costmap);       // snapshot of the map as it was
+        windowed.setMaxArrivalInformation();
+        ShardedScorer sharded({0, 0});
+        fs_ray_params rp{};
+        rp.max_camera_depth = 2.0; rp.delta_theta = 0.10; rp.camera_fov = 1.04; rp.robot_radius = 0.60;
+        rp.n_elev = 1; rp.obst_min = 240; rp.obst_max = 254; rp.trace_min = 255; rp.trace_max = 255; rp.factor_max = 1.2; rp.factor_min = 0.70;
+        for (int k = 0; k < 4; ++k) rp.polygon[k] = poly[k];
+        sharded.setRayParams(rp);
+        sharded.updateCostmap(*costmap);
+        sharded.setMaxArrivalInformation();
+        int bad = 0;
+        const int wins[3][4] = {{nx / 3, ny / 4, nx / 3 + 37, ny / 4 + 21}, {0, ny - 13, 29, ny}, {nx - 9, 3, nx, 50 < ny ? 50 : ny}};
+        for (const auto &b : wins) {
+            for (int j = b[1]; j < b[3]; ++j)
+                for (int i = b[0]; i < b[2]; ++i)
+                    costmap->getCharMap()[(size_t)j * nx + i] = (uint8_t)(((i * 7 + j * 13) % 5 == 0) ? 254 : ((i + j) % 3 == 0 ? 0 : 255));
+            windowed.updateCostmapWindow(b[0], b[1], b[2], b[3]);
+            sharded.updateCostmapWindow(*costmap, b[0], b[1], b[2], b[3]);
+            FrontierCostCalculator snap(std::make_shared<ScoringContext>(0), costmap);       // snapshot of the rewritten map
+            snap.setMaxArrivalInformation();
+            auto a = fresh_list(), c = fresh_list();
+            windowed.setArrivalInformationForFrontiers(a, poly_v);
+            snap.setArrivalInformationForFrontiers(c, poly_v);
+            std::vector<double> g3(3 * (size_t)n, 0.0);
+            for (int32_t i = 0; i < n; ++i) { g3[3 * i] = goals[2 * i]; g3[3 * i + 1] = goals[2 * i + 1]; }
+            std::vector<int32_t> arr(n), amax(n), st(n); std::vector<double> yw(n); std::vector<uint8_t> ac(n);
+            sharded.check(fs_multi_score_arrival(sharded.get(), n, g3.data(), sizes.data(), nullptr, nullptr, nullptr, arr.data(), amax.data(), yw.data(), ac.data(), st.data()),
+                          "fs_multi_score_arrival");
+            for (int32_t i = 0; i < n; ++i) {
+                bad += a[i]->getArrivalInformation() != c[i]->getArrivalInformation();
+                bad += a[i]->getGoalYaw() != c[i]->getGoalYaw();
+                bad += a[i]->isAchievable() != c[i]->isAchievable();
+                bad += (double)arr[i] != c[i]->getArrivalInformation();
+                bad += (ac[i] != 0) != c[i]->isAchievable();
+            }
+        }
+        printf("updateCostmapWindow (3 windows, one context and ShardedScorer({0,0})): %d mismatches against whole-map snapshots\n", bad);
+        if (bad) ++failures;
+        std::memcpy(costmap->getCharMap(), saved.data(), saved.size());
+    }
+
     // error behaviour of the reference interface
     failures += expect_throw("Frontier getter on unset field", [] { Frontier fr; (void)fr.getArrivalInformation(); });
     failures += expect_throw("duplicate frontiers", [&] {

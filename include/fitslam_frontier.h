@@ -127,6 +127,20 @@ int fs_upload_grid(fs_ctx *ctx, const uint8_t *cells, int32_t nx, int32_t ny, in
 int fs_upload_grid_bricks(fs_ctx *ctx, int32_t nx, int32_t ny, int32_t nz, const double origin_xyz[3], double resolution,
                           uint8_t default_value, int64_t n_bricks, const int32_t *brick_xyz, const uint8_t *brick_cells);
 
+/* A WINDOW of the staged map rewritten in place — what a costmap update cycle does to the master grid: every layer's
+ * `updateCosts(master_grid, min_i, min_j, max_i, max_j)` writes only inside the cycle's bounds through `getCharMap()` (the
+ * reference's own layers: DEP/src/nav2_plugins/lethal_marker.cpp:305-325, fit_slam2_nav2_plugins/plugins/keepout_layer.cpp:279-300;
+ * the costmap is a rolling / bounded-update one, fit_slam2/params/active_slam_nav2_params.yaml:124).  The window is cells
+ * [x0, x0+sx) x [y0, y0+sy) x [z0, z0+sz) of the grid fs_upload_grid staged (same shape, origin and resolution: a map that
+ * moved or was resized is a new snapshot).  `cells` points at the window's first cell, x fastest; row_stride / slice_stride are
+ * the byte distances between its rows / z slices — pass `getCharMap() + y0 * size_x + x0` with row_stride = size_x to send a
+ * window of the live costmap without packing it; 0 = tightly packed (sx, sx * sy).  Images derived from the grid are updated
+ * for the bricks the window touches only; cached arrival limits stay (setMaxArrivalInformation's fan does not depend on the
+ * cells, DEP/src/CostCalculator.cpp:123-191).  Scoring afterwards equals scoring after fs_upload_grid of the whole rewritten
+ * map, bit for bit.  An empty window is a no-op; one that leaves the grid is refused (FS_E_INVALID), nothing written. */
+int fs_update_grid_region(fs_ctx *ctx, int32_t x0, int32_t y0, int32_t z0, int32_t sx, int32_t sy, int32_t sz,
+                          const uint8_t *cells, int64_t row_stride, int64_t slice_stride);
+
 /* Frontier-cell predicate of FrontierSearch::isNewFrontierCell (DEP/src/FrontierSearch.cpp:218-249; isFree / isLethal /
  * isUnknown: DEP/include/.../FrontierSearch.hpp:129-142; frontierSearch/lethal_threshold 160) evaluated for every cell
  * of the staged grid, slice by slice: unknown cell, no lethal in-plane 4-neighbour, at least one free one.
@@ -303,6 +317,8 @@ int  fs_multi_shard_bounds(int32_t n, int n_shards, int shard, int32_t *lo, int3
 int  fs_multi_set_option(fs_multi *m, const char *key, double value);
 int  fs_multi_set_ray_params(fs_multi *m, const fs_ray_params *p);
 int  fs_multi_upload_grid(fs_multi *m, const uint8_t *cells, int32_t nx, int32_t ny, int32_t nz, const double origin_xyz[3], double resolution);
+int  fs_multi_update_grid_region(fs_multi *m, int32_t x0, int32_t y0, int32_t z0, int32_t sx, int32_t sy, int32_t sz,
+                                 const uint8_t *cells, int64_t row_stride, int64_t slice_stride);   /* the window on every device */
 int  fs_multi_upload_landmarks(fs_multi *m, const float *xyz, int32_t n_landmarks);
 int  fs_multi_lookup_generate(fs_multi *m, const float bounds[6]);
 int  fs_multi_lookup_load(fs_multi *m, const char *path);

@@ -91,6 +91,9 @@ def test_get_frontier_costs_and_pose_safety(fs, oracle, ref_table, tmp_path, see
     assert "ShardedScorer({0,0}): 2 devices, 0 mismatches" in p.stdout
     # CostAssigner::getFrontierCosts as ONE device call (planner first, fs_get_frontier_costs): every response field bit for bit
     assert "getFrontierCosts through fs_get_frontier_costs: 0 mismatches" in p.stdout
+    # a costmap update cycle between two ticks: only the rewritten windows are sent (updateCostmapWindow -> fs_update_grid_region,
+    # on one context and on both members of a ShardedScorer); arrival / yaw / achievability as from whole-map snapshots
+    assert "updateCostmapWindow (3 windows, one context and ShardedScorer({0,0})): 0 mismatches" in p.stdout
 
     G = oracle.Grid(w.cells, origin=w.origin, resolution=w.resolution)
     P = oracle.RayParams(polygon=poly32)
