@@ -843,6 +843,39 @@ def run_rank(args) -> int:
         extra["rank_candidates_call"] = {"ms_per_call": (time.perf_counter() - t0) / 5 * 1e3,
                                          "note": "fs_rank_candidates over one step's records: utilities, weighted cost and order, host columns both ways"}
 
+    # ---- the map between two ticks: a costmap update cycle rewrites one window of the master grid (Layer::updateCosts' bounds,
+    # DEP/src/nav2_plugins/lethal_marker.cpp:305-325); fs_update_grid_region sends that window alone, fs_upload_grid the whole map.
+    # Each followed by one scoring step (the snapshot's re-cuts the whole class image, the window's nothing but its bricks).  The
+    # window holds the cells the map already has there, so the timed loop's map — and every figure above — is unchanged.
+    if not multi_path and not args.no_parity and wl_name != "C5":
+        nz_, ny_, nx_ = w.cells.shape
+        sx_, sy_, sz_ = min(64, nx_), min(64, ny_), min(16, nz_)
+        x0_, y0_, z0_ = (nx_ - sx_) // 2, (ny_ - sy_) // 2, (nz_ - sz_) // 2
+        view = w.cells[z0_:z0_ + sz_, y0_:y0_ + sy_, x0_:x0_ + sx_]
+
+        def timed(fn, reps=5):
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                fn()
+                sc.score_candidates_dev(n_local, d_goal.data_ptr(), d_fsize.data_ptr(), d_black.data_ptr(), 0, d_recs[0].data_ptr())
+                torch.cuda.synchronize(dev)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts))
+
+        def snapshot():
+            sc.upload_grid(w.cells, w.origin, w.resolution)
+            sc.set_arrival_limits(mx["max_gt"], mx["min_gt"])
+
+        t_none = timed(lambda: None)
+        t_win = timed(lambda: sc.update_grid_region(x0_, y0_, z0_, view, view=True))
+        t_snap = timed(snapshot)
+        extra["map_update_then_step"] = {"step_alone_ms": t_none, "window_then_step_ms": t_win, "snapshot_then_step_ms": t_snap,
+                                         "window": [sx_, sy_, sz_], "grid_bytes": int(w.cells.size),
+                                         "note": "fs_update_grid_region of one window (from a strided view of the host map) / fs_upload_grid of the whole map, "
+                                                 "each followed by one synchronised scoring step; medians of 5; host map in pageable memory"}
+
     if not multi_path and not args.no_parity:
         extra["reference_request_visibility" if args.fim_angle < np.pi else "build_cone_visibility"] = other_visibility(
             args, sc, w, n_local, d_goal, d_fsize, d_black, torch.zeros_like(d_recs[0]), dev, mx, arrival_kw)

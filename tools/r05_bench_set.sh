@@ -24,3 +24,4 @@ run rehearse_multi_one_rank_rccl_bench python3 bench.py --rehearse-multi
 run latency_operating_point python3 bench.py --latency --latency-calls 500
 run latency_reference_request python3 bench.py --latency --latency-calls 500 --fim-angle 4.0
 run gloo2_rehearsal_bench python3 bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --repeats 3 --min-timed-seconds 0
+run grid_region_update python3 tools/grid_region_probe.py
