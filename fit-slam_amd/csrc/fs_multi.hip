@@ -222,7 +222,7 @@ int fs_multi_upload_landmarks(fs_multi *m, const float *xyz, int32_t n_landmarks
 {
     if (!m || (n_landmarks > 0 && !xyz) || n_landmarks < 0) return FS_E_INVALID;
     if (n_landmarks > 2000000) return multi_fail(m, FS_E_INVALID, "at most 2,000,000 landmarks per context");
-    // the k-d ordering and the chunk spheres are a function of the cloud alone: once, on the calling thread (11.7 ms at C3);
+    // the k-d ordering and the chunk spheres are a function of the cloud alone: once (4.3 ms at C3, the ordering's top levels on threads of their own);
     // then every device takes its copy at the same time
     FsStagedCloud staged;
     fs_stage_landmarks(xyz, n_landmarks, staged);
