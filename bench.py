@@ -451,6 +451,36 @@ def run_latency(args) -> int:
             fr = O.frontier_search(w.cells, w.origin, w.resolution, pos)
             res["frontier_clusters_with_labels"]["cpu_oracle_searchFrom_us"] = (time.perf_counter() - t0) * 1e6
             res["frontier_clusters_with_labels"]["frontier_records"] = int(len(fr["sizes"]))
+        # One whole behaviour-tree tick of a LIVE system: the costmap cycle rewrote a window, the SLAM map changed (the whole cloud
+        # is staged again: k-d ordering on the host + transfer), then ProcessFrontierCosts (the cost assignment of 50 frontiers as one
+        # call) and EvaluateFisherInformation (isPoseSafe for one pose).  The window and the cloud hold what is already staged, so
+        # every other figure of this run is unaffected.
+        n = 50
+        g, f, b = w.goals[:n], w.frontier_size[:n], w.blacklisted[:n]
+        pl = np.hypot(g[:, 0], g[:, 1]) + 0.5
+        ph = np.abs(np.arctan2(g[:, 1], g[:, 0]))
+        sc.set_arrival_limits(max(mx["max_gt"], 1000.0) * 4, mx["min_gt"])
+        side = min(128, w.cells.shape[2], w.cells.shape[1])
+        win = w.cells[:, :side, :side]
+        parts = {"window": [], "cloud": [], "costs": [], "pose": [], "tick": []}
+        for it in range(20 + max(50, args.latency_calls // 5)):
+            t0 = time.perf_counter()
+            sc.update_grid_region(0, 0, 0, win, view=True)
+            t1 = time.perf_counter()
+            sc.upload_landmarks(w.landmarks)
+            t2 = time.perf_counter()
+            sc.get_frontier_costs(g, pl, ph, f, b, with_fim=False)
+            t3 = time.perf_counter()
+            sc.score_fim(pose, info_only=True)
+            t4 = time.perf_counter()
+            if it >= 20:
+                for k, v in zip(("window", "cloud", "costs", "pose", "tick"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t4 - t0)):
+                    parts[k].append(v * 1e6)
+        sc.set_arrival_limits(mx["max_gt"], mx["min_gt"])
+        res["live_tick_50_frontiers_1_pose"] = {"tick": _percentiles(parts["tick"]),
+                                                "p50_us": {k: float(np.median(v)) for k, v in parts.items()},
+                                                "window": [side, side, int(w.cells.shape[0])], "landmarks_restaged": int(w.landmarks.shape[0]),
+                                                "note": "fs_update_grid_region + fs_upload_landmarks (whole cloud) + fs_get_frontier_costs (50 frontiers) + fs_score_fim (1 pose, info only), synchronised calls back to back"}
         sc.close()
         out["workloads"][wl] = res
     print(json.dumps(out), flush=True)
