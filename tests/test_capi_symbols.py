@@ -210,3 +210,22 @@ def test_headers_are_plain_c_and_a_c_program_links_against_the_library(tmp_path,
     res = subprocess.run([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe), lib, f"-Wl,-rpath,{os.path.dirname(lib)}",
                           "-Wl,--unresolved-symbols=ignore-in-shared-libs"], capture_output=True, text=True)
     assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_window_arguments_of_the_binding(fs):
+    """fs_update_grid_region through the binding: a packed window passes (0, 0) strides; a numpy VIEW into the caller's whole map
+    passes the view's pointer and strides (nothing is copied); 2-D windows get a z extent of one.  Host logic only."""
+    import numpy as np
+    cells = np.arange(4 * 10 * 12, dtype=np.uint8).reshape(4, 10, 12)
+    ptr, sx, sy, sz, rs, ss, keep = fs.capi._window_args(cells[1:3, 2:7, 3:8].copy(), False)
+    assert (sx, sy, sz, rs, ss) == (5, 5, 2, 0, 0) and keep.flags["C_CONTIGUOUS"]
+    view = cells[1:3, 2:7, 3:8]
+    ptr, sx, sy, sz, rs, ss, keep = fs.capi._window_args(view, True)
+    assert (sx, sy, sz, rs, ss) == (5, 5, 2, 12, 120) and ptr.value == view.ctypes.data and keep.base is not None
+    ptr, sx, sy, sz, rs, ss, keep = fs.capi._window_args(cells[0, 4:5, 2:9], True)               # one row of a 2-D map
+    assert (sx, sy, sz, rs, ss) == (7, 1, 1, 0, 0)
+    ptr, sx, sy, sz, rs, ss, keep = fs.capi._window_args(np.zeros((0, 7), dtype=np.uint8), True)  # empty
+    assert (sx, sy, sz) == (7, 0, 1)
+    import pytest
+    with pytest.raises(ValueError):
+        fs.capi._window_args(cells[:, :, ::2], True)                                              # not contiguous along x
