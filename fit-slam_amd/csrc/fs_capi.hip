@@ -1007,7 +1007,8 @@ int fs_update_grid_region(fs_ctx *c, int32_t x0, int32_t y0, int32_t z0, int32_t
     if (!c->have_grid) return fail(c, FS_E_STATE, "fs_upload_grid has not been called");
     if (sx < 0 || sy < 0 || sz < 0) return fail(c, FS_E_INVALID, "negative window size");
     if (x0 < 0 || y0 < 0 || z0 < 0 || (int64_t)x0 + sx > c->nx || (int64_t)y0 + sy > c->ny || (int64_t)z0 + sz > c->nz)
-        return fail(c, FS_E_INVALID, "window [%d,%d) x [%d,%d) x [%d,%d) leaves the %d x %d x %d grid", x0, x0 + sx, y0, y0 + sy, z0, z0 + sz, c->nx, c->ny, c->nz);
+        return fail(c, FS_E_INVALID, "window [%d,%lld) x [%d,%lld) x [%d,%lld) leaves the %d x %d x %d grid", x0, (long long)x0 + sx, y0, (long long)y0 + sy,
+                    z0, (long long)z0 + sz, c->nx, c->ny, c->nz);
     if (sx == 0 || sy == 0 || sz == 0) return FS_OK;
     if (!cells) return FS_E_INVALID;
     if (row_stride == 0) row_stride = sx;

@@ -149,3 +149,41 @@ def test_window_update_on_every_member_of_a_multi_device_scorer(fs):
                 np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     finally:
         one.close(); multi.close()
+
+
+@pytest.mark.parametrize("name,seed", [("REF2D", 11), ("C2", 12)])
+def test_map_windows_between_random_calls_equal_new_snapshots(fs, name, seed):
+    """Random call sequences (every entry point, list lengths from 1 to 400, split settings, the optional routes of the small calls
+    — captured launch graphs among them: a window update is a context epoch) with random map windows in between: the context that
+    receives the windows must answer like one that takes a whole new snapshot each time."""
+    from test_gpu_lifecycle import KINDS, _call, _compare, _make
+    w = fs.synth.make_workload(name, n_cand=400)
+    rng = np.random.default_rng(seed)
+    cells = np.array(w.cells, dtype=np.uint8, copy=True)
+    snap, limits = _make(fs, w)
+    win, _ = _make(fs, w, limits)
+    try:
+        first = snap.score_arrival(w.goals, w.frontier_size, w.blacklisted)
+        poses = fs.synth.poses_from_yaw(w.goals, first["yaw"])
+        for step in range(40):
+            if step % 2 == 0:
+                for _ in range(int(rng.integers(1, 3))):
+                    x0, y0, z0, vals = _random_window(rng, cells.shape, 48)
+                    cells[z0:z0 + vals.shape[0], y0:y0 + vals.shape[1], x0:x0 + vals.shape[2]] = vals
+                    win.update_grid_region(x0, y0, z0, cells[z0:z0 + vals.shape[0], y0:y0 + vals.shape[1], x0:x0 + vals.shape[2]], view=True)
+                snap.upload_grid(cells, w.origin, w.resolution)
+                snap.set_arrival_limits(limits["max_gt"], limits["min_gt"])
+            kind = str(rng.choice(KINDS))
+            n = int(rng.choice([1, 3, 9, 17, 50, 64, 200, 400]))
+            pick = rng.choice(w.goals.shape[0], size=n, replace=False)
+            split = int(rng.choice([0, 3, 4]))
+            angle = float(rng.choice([1.0, 4.0]))
+            opts = {k: int(rng.integers(0, 2)) for k in ("graph", "zerocopy", "fim.hostfinish")}
+            for k, v in opts.items():
+                win.set_option(k, v)
+            if step % 5 == 0:
+                win.set_option("ray.layout", int(rng.choice([0, 1, 2])))
+            what = f"{name} seed {seed} step {step}: {kind} n={n} split={split} angle={angle} {opts}"
+            _compare(fs, kind, _call(fs, win, kind, w, pick, poses, split, angle), _call(fs, snap, kind, w, pick, poses, split, angle), what)
+    finally:
+        snap.close(); win.close()
