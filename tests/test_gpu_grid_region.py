@@ -7,10 +7,14 @@ bit for bit — per-ray counts included — through both walks (row-major bytes 
 for the window only), in 2-D and 3-D, for windows that are not brick-aligned, touch the map's border or are handed over as a
 strided view of the caller's whole map; and both equal the oracle on the rewritten map.
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+SCALE = int(os.environ.get("FS_WINDOW_SCALE", "1"))      # by hand: FS_WINDOW_SCALE=100 multiplies the number of update cycles
 
 FS_E_INVALID, FS_E_STATE = -1, -4
 
@@ -59,7 +63,7 @@ def test_window_updates_equal_a_fresh_snapshot(fs, oracle, case):
         upd.upload_grid(cells, w.origin, w.resolution)
         mx = upd.max_arrival()
         upd.score_arrival(w.goals, w.frontier_size, w.blacklisted)       # (the class image exists before the first window arrives)
-        for step in range(12):
+        for step in range(12 * SCALE):
             k = int(rng.integers(1, 4))
             for _ in range(k):                                           # a cycle may rewrite several windows, overlapping ones too
                 x0, y0, z0, vals = _random_window(rng, cells.shape, 23)
@@ -165,7 +169,7 @@ def test_map_windows_between_random_calls_equal_new_snapshots(fs, name, seed):
     try:
         first = snap.score_arrival(w.goals, w.frontier_size, w.blacklisted)
         poses = fs.synth.poses_from_yaw(w.goals, first["yaw"])
-        for step in range(40):
+        for step in range(40 * SCALE):
             if step % 2 == 0:
                 for _ in range(int(rng.integers(1, 3))):
                     x0, y0, z0, vals = _random_window(rng, cells.shape, 48)
