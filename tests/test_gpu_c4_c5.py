@@ -177,5 +177,18 @@ def test_grid_beyond_2_31_cells_walks_like_the_same_cells_in_a_small_grid(fs):
                 np.testing.assert_array_equal(got[k], want[lay][k], err_msg=f"layout {lay}: {k}")
             np.testing.assert_array_equal(got["yaw"], want[lay]["yaw"])
         np.testing.assert_array_equal(want[1]["ray_counts"], want[2]["ray_counts"])
+        # ... and a costmap cycle's WINDOW out there (fs_update_grid_region: cell offsets past 2^31 in the scatter, brick addresses at
+        # the far end of the class image in the partial re-cut): the corner block blanked to unknown, then written back in two
+        # unaligned windows — the class image exists (layout 2 has just walked it), so it is the partial re-cut that runs
+        s.update_grid_region(x0, y0, z0, np.full((n, n, n), 255, dtype=np.uint8))
+        blank = s.score_arrival(goals, w.frontier_size, w.blacklisted)
+        assert not np.array_equal(blank["ray_counts"], want[2]["ray_counts"]) and (blank["ray_counts"] >= want[2]["ray_counts"]).all()
+        s.update_grid_region(x0, y0, z0, sub[:, :, :37])
+        s.update_grid_region(x0 + 37, y0, z0, sub[:, :, 37:], view=True)
+        for lay in (2, 1):
+            s.set_option("ray.layout", lay)
+            got = s.score_arrival(goals, w.frontier_size, w.blacklisted)
+            for k in ("status", "arrival", "argmax", "achievable", "ray_counts", "yaw"):
+                np.testing.assert_array_equal(got[k], want[lay][k], err_msg=f"after the windows, layout {lay}: {k}")
     finally:
         s.close()
