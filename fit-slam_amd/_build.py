@@ -12,7 +12,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["fs_raymarch.hip", "fs_fim.hip", "fs_rank.hip", "fs_sort.hip", "fs_gridops.hip", "fs_frontier.hip", "fs_keyframes.hip", "fs_multi.hip", "fs_capi.hip"]
+SOURCES = ["fs_raymarch.hip", "fs_fim.hip", "fs_rank.hip", "fs_sort.hip", "fs_gridops.hip", "fs_cloud.hip", "fs_frontier.hip", "fs_keyframes.hip", "fs_multi.hip", "fs_capi.hip"]
 HEADERS = ["fs_internal.h", os.path.join("..", "..", "include", "fitslam_frontier.h"), os.path.join("..", "..", "include", "fitslam_frontier_dev.h")]
 
 # -ffp-contract=off: the ray set-up (fp64) and the landmark transform (fp32) must round exactly like

@@ -261,6 +261,14 @@ struct fs_ctx {
     DevBuf<uint8_t> d_fc_visited;
     DevBuf<fs_frontier_cluster> d_fc_clusters;
     DevBuf<long long> d_fc_sums;
+    // "cloud.order" 1 (default): the landmark cloud's k-d leaf order is computed on the device (fs_cloud.hip: fs_upload_landmarks 1.2 ms
+    // at C3's 100 k landmarks, 4.4 ms at 500 k; the host form, "cloud.order" 0, 4.4 / 20.2 ms with its top levels on threads of their
+    // own, 13.3 / 78.9 ms on one thread — tools/landmark_staging_probe.py); scratch of that path
+    bool opt_cloud_device = true;
+    DevBuf<float> d_cloud_raw;
+    DevBuf<int32_t> d_cloud_perm, d_cloud_bounds;
+    DevBuf<uint64_t> d_cloud_keys;
+    DevBuf<char> d_cloud_temp;
     bool opt_sort = true;
     bool opt_sort_reverse = false; // development: blocks in reverse Morton order (order-sensitivity measurements)
     bool opt_costmap = true;       // the spatial sort puts the blocks that were expensive in the previous call first ("sort.costmap")
@@ -836,6 +844,7 @@ void fs_ctx_destroy(fs_ctx *c)
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->sort_scratch) (void)hipFree(c->sort_scratch);
     c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release(); c->h_fin.release(); c->h_win.release(); c->d_win.release();
+    c->d_cloud_raw.release(); c->d_cloud_perm.release(); c->d_cloud_bounds.release(); c->d_cloud_keys.release(); c->d_cloud_temp.release();
     c->d_seg_start.release(); c->d_seg_end.release(); c->d_tri.release(); c->d_seg_ok.release(); c->d_seg_hit.release();
     c->d_mask.release(); c->d_brick_cells.release(); c->d_seg_traced.release(); c->d_seg_unknown.release();
     c->d_seg_all.release(); c->d_brick_xyz.release(); c->d_bad.release(); c->d_count.release();
@@ -1545,6 +1554,59 @@ int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st)
     return FS_OK;
 }
 
+bool fs_ctx_cloud_on_device(const fs_ctx *c) { return c && c->opt_cloud_device; }
+
+// "cloud.order" 1: the raw cloud goes up as it is and the device puts it into k-d leaf order (fs_cloud.hip) — the host only finds
+// out how many landmarks are usable (the level layout depends on that number) and which, if any, are not.
+static int upload_landmarks_device_order(fs_ctx *c, const float *xyz, int32_t m)
+{
+    FS_HIP(c, hipSetDevice(c->device));
+    auto ok = [&](int32_t i) {                                    // as fs_stage_landmarks: finite and within 1e17 m (fabsf of a NaN compares false)
+        const float *p = xyz + 3 * (size_t)i;
+        return std::fabs(p[0]) <= 1.0e17f && std::fabs(p[1]) <= 1.0e17f && std::fabs(p[2]) <= 1.0e17f;
+    };
+    int32_t n_usable = 0;
+    for (int32_t i = 0; i < m; ++i) n_usable += ok(i) ? 1 : 0;
+    std::vector<int32_t> usable;                                  // the usable landmarks in input order — only when some are not (rare)
+    if (n_usable != m) {
+        usable.reserve((size_t)n_usable);
+        for (int32_t i = 0; i < m; ++i) if (ok(i)) usable.push_back(i);
+    }
+    const bool all_usable = n_usable == m;
+    const int32_t n_chunks = std::max<int32_t>(1, (m + FS_CHUNK - 1) / FS_CHUNK);
+    const size_t mp = (size_t)n_chunks * FS_CHUNK;
+    std::vector<int32_t> bounds, level_off, level_nodes;
+    fs_cloud_levels(n_usable, bounds, level_off, level_nodes);
+    const size_t temp_bytes = fs_cloud_sort_temp_bytes(n_usable, c->stream);
+    FS_HIP(c, c->d_lx.ensure(mp)); FS_HIP(c, c->d_ly.ensure(mp)); FS_HIP(c, c->d_lz.ensure(mp));
+    FS_HIP(c, c->d_spheres.ensure((size_t)n_chunks * 4));
+    FS_HIP(c, c->d_cloud_raw.ensure(3 * (size_t)std::max(m, 1)));
+    FS_HIP(c, c->d_cloud_perm.ensure(2 * (size_t)std::max(n_usable, 1)));
+    FS_HIP(c, c->d_cloud_keys.ensure(2 * (size_t)std::max(n_usable, 1)));
+    FS_HIP(c, c->d_cloud_bounds.ensure(std::max<size_t>(bounds.size(), 1)));
+    FS_HIP(c, c->d_cloud_temp.ensure(std::max<size_t>(temp_bytes, 256)));
+    if (m > 0) FS_HIP(c, hipMemcpyAsync(c->d_cloud_raw.p, xyz, sizeof(float) * 3 * (size_t)m, hipMemcpyHostToDevice, c->stream));
+    if (!bounds.empty()) FS_HIP(c, hipMemcpyAsync(c->d_cloud_bounds.p, bounds.data(), sizeof(int32_t) * bounds.size(), hipMemcpyHostToDevice, c->stream));
+    int32_t *perm_a = c->d_cloud_perm.p, *perm_b = perm_a + std::max(n_usable, 1);
+    if (all_usable) FS_HIP(c, fs_cloud_iota(perm_a, n_usable, c->stream));
+    else if (n_usable > 0) FS_HIP(c, hipMemcpyAsync(perm_a, usable.data(), sizeof(int32_t) * (size_t)n_usable, hipMemcpyHostToDevice, c->stream));
+    int32_t *perm = perm_a;
+    FS_HIP(c, fs_cloud_order_device(c->d_cloud_raw.p, n_usable, c->d_cloud_bounds.p, level_off, level_nodes, perm_a, perm_b, c->d_cloud_keys.p,
+                                    c->d_cloud_keys.p + std::max(n_usable, 1), c->d_cloud_temp.p, temp_bytes, c->stream, &perm));
+    FS_HIP(c, fs_cloud_finish(c->d_cloud_raw.p, perm, n_usable, n_chunks, c->d_lx.p, c->d_ly.p, c->d_lz.p, c->d_spheres.p, c->stream));
+    FS_HIP(c, hipStreamSynchronize(c->stream));                  // (the caller's cloud and the vectors above are read until here)
+    if (c->d_cloud_raw.cap > ((size_t)16 << 20)) { c->d_cloud_raw.release(); c->d_cloud_perm.release(); c->d_cloud_keys.release(); c->d_cloud_temp.release(); }
+    c->m = m; c->n_chunks = n_chunks;
+    reset_voxel_ratio(c);
+    int gb = 12;
+    while ((1ll << gb) < 2ll * std::max(m, 1)) ++gb;
+    c->ghash_bits = gb;
+    FS_HIP(c, c->d_gtable.ensure((size_t)fs_ctx::kPool << gb));
+    c->have_lm = true;
+    ++c->epoch;
+    return FS_OK;
+}
+
 extern "C" {
 
 int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
@@ -1552,6 +1614,7 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
     if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
     // chunk masks live in LDS (one bit per chunk) next to the 64-KiB tier-1 table
     if (m > 2000000) return fail(c, FS_E_INVALID, "at most 2,000,000 landmarks per context");
+    if (c->opt_cloud_device) return upload_landmarks_device_order(c, xyz, m);
     FsStagedCloud st;
     fs_stage_landmarks(xyz, m, st);
     return fs_upload_staged_landmarks(c, st);
@@ -1566,6 +1629,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.specialise") == 0) { c->opt_special = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.learn") == 0) { c->opt_learn = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "cloud.order") == 0) { c->opt_cloud_device = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }
