@@ -261,10 +261,12 @@ struct fs_ctx {
     DevBuf<uint8_t> d_fc_visited;
     DevBuf<fs_frontier_cluster> d_fc_clusters;
     DevBuf<long long> d_fc_sums;
-    // "cloud.order" 1 (default): the landmark cloud's k-d leaf order is computed on the device (fs_cloud.hip: fs_upload_landmarks 1.2 ms
-    // at C3's 100 k landmarks, 4.4 ms at 500 k; the host form, "cloud.order" 0, 4.4 / 20.2 ms with its top levels on threads of their
-    // own, 13.3 / 78.9 ms on one thread — tools/landmark_staging_probe.py); scratch of that path
-    bool opt_cloud_device = true;
+    // "cloud.order": where the landmark cloud is put into its k-d leaf order — 0 on the host, 2 on the device (fs_cloud.hip), 1 (default)
+    // on the device from FS_CLOUD_DEVICE_FROM landmarks on: fs_upload_landmarks 1.2 ms at C3's 100 k landmarks, 4.4 ms at 500 k on the
+    // device (the host form: 4.4 / 20.2 ms with its top levels on threads of their own, 13.3 / 78.9 ms on one thread —
+    // tools/landmark_staging_probe.py); a level costs the device ~ 0.03 ms of launches whatever its size, so a 2 k cloud is faster
+    // on the host (0.06 against 0.18 ms).  Scratch of the device path below.
+    int opt_cloud_order = 1;
     DevBuf<float> d_cloud_raw;
     DevBuf<int32_t> d_cloud_perm, d_cloud_bounds;
     DevBuf<uint64_t> d_cloud_keys;
@@ -1554,7 +1556,8 @@ int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st)
     return FS_OK;
 }
 
-bool fs_ctx_cloud_on_device(const fs_ctx *c) { return c && c->opt_cloud_device; }
+#define FS_CLOUD_DEVICE_FROM 4096
+bool fs_ctx_cloud_on_device(const fs_ctx *c, int32_t m) { return c && (c->opt_cloud_order == 2 || (c->opt_cloud_order == 1 && m >= FS_CLOUD_DEVICE_FROM)); }
 
 // "cloud.order" 1: the raw cloud goes up as it is and the device puts it into k-d leaf order (fs_cloud.hip) — the host only finds
 // out how many landmarks are usable (the level layout depends on that number) and which, if any, are not.
@@ -1614,7 +1617,7 @@ int fs_upload_landmarks(fs_ctx *c, const float *xyz, int32_t m)
     if (!c || (m > 0 && !xyz) || m < 0) return FS_E_INVALID;
     // chunk masks live in LDS (one bit per chunk) next to the 64-KiB tier-1 table
     if (m > 2000000) return fail(c, FS_E_INVALID, "at most 2,000,000 landmarks per context");
-    if (c->opt_cloud_device) return upload_landmarks_device_order(c, xyz, m);
+    if (fs_ctx_cloud_on_device(c, m)) return upload_landmarks_device_order(c, xyz, m);
     FsStagedCloud st;
     fs_stage_landmarks(xyz, m, st);
     return fs_upload_staged_landmarks(c, st);
@@ -1629,7 +1632,7 @@ int fs_set_option(fs_ctx *c, const char *key, double value)
     if (std::strcmp(key, "fim.cull") == 0) { c->opt_cull = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.specialise") == 0) { c->opt_special = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "fim.learn") == 0) { c->opt_learn = value != 0.0; return FS_OK; }
-    if (std::strcmp(key, "cloud.order") == 0) { c->opt_cloud_device = value != 0.0; return FS_OK; }
+    if (std::strcmp(key, "cloud.order") == 0 && value >= 0 && value <= 2) { c->opt_cloud_order = (int)value; return FS_OK; }
     if (std::strcmp(key, "ray.sort") == 0) { c->opt_sort = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.costmap") == 0) { c->opt_costmap = value != 0.0; return FS_OK; }
     if (std::strcmp(key, "sort.reverse") == 0) { c->opt_sort_reverse = value != 0.0; return FS_OK; }

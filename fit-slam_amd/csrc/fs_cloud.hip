@@ -1,4 +1,4 @@
-// fs_cloud.hip — the landmark cloud's k-d leaf order computed on the device ("cloud.order" 1).
+// fs_cloud.hip — the landmark cloud's k-d leaf order computed on the device ("cloud.order" 2, and 1 from 4096 landmarks on).
 //
 // What fs_stage_landmarks (fs_capi.hip) does on the host — the cloud in the leaf order of a k-d tree with exactly 64 landmarks per
 // leaf, split along the longest axis of a node's bounding box at the multiple of 64 nearest the median — level by level on the GPU.

@@ -140,9 +140,9 @@ struct FsStagedCloud {
 };
 void fs_stage_landmarks(const float *xyz, int32_t m, FsStagedCloud &out);
 int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st);
-// ... and the same ordering computed on the device ("cloud.order" 1, fs_cloud.hip): every level's node boundaries (a function of the
+// ... and the same ordering computed on the device ("cloud.order", fs_cloud.hip): every level's node boundaries (a function of the
 // number of usable landmarks alone), the level loop (keys kernel + one stable radix sort per level), the SoA gather and the spheres
-bool fs_ctx_cloud_on_device(const fs_ctx *c);
+bool fs_ctx_cloud_on_device(const fs_ctx *c, int32_t m);
 void fs_cloud_levels(int32_t n_usable, std::vector<int32_t> &bounds, std::vector<int32_t> &level_off, std::vector<int32_t> &level_nodes);
 size_t fs_cloud_sort_temp_bytes(int32_t n, hipStream_t s);
 hipError_t fs_cloud_iota(int32_t *d_perm, int32_t n, hipStream_t s);

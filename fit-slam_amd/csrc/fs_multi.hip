@@ -224,8 +224,8 @@ int fs_multi_upload_landmarks(fs_multi *m, const float *xyz, int32_t n_landmarks
     if (n_landmarks > 2000000) return multi_fail(m, FS_E_INVALID, "at most 2,000,000 landmarks per context");
     // the k-d ordering and the chunk spheres are a function of the cloud alone: once (4.3 ms at C3, the ordering's top levels on threads of their own);
     // then every device takes its copy at the same time
-    // ("cloud.order" 1: every member orders its own copy on its device, all at once — the same order on each)
-    if (!m->ctx.empty() && fs_ctx_cloud_on_device(m->ctx[0]))
+    // (the ordering on the device, "cloud.order": every member orders its own copy, all at once — the same order on each)
+    if (!m->ctx.empty() && fs_ctx_cloud_on_device(m->ctx[0], n_landmarks))
         return for_all_parallel(m, "fs_upload_landmarks", [&](fs_ctx *c) { return fs_upload_landmarks(c, xyz, n_landmarks); });
     FsStagedCloud staged;
     fs_stage_landmarks(xyz, n_landmarks, staged);

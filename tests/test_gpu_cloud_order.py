@@ -1,4 +1,4 @@
-"""The landmark cloud's k-d leaf order computed on the device ("cloud.order" 1, fs_cloud.hip) against the host form
+"""The landmark cloud's k-d leaf order computed on the device ("cloud.order" 2; the default, 1, takes it from 4096 landmarks on; fs_cloud.hip) against the host form
 (fs_stage_landmarks): the order of the cloud is the library's own business — what must not change is what comes out.  Integer
 columns (visible landmarks, voxels) are order-independent and must agree bit for bit; float columns follow the order of summation
 and must agree within 1e-5 relative (north_star's tolerance is 1e-4); the chunk cull must test about as many landmarks (same split
@@ -13,7 +13,7 @@ def _pair(fs, lm, angle=1.0, multi=False):
     host = fs.FrontierScorer(device=0)
     dev = fs.MultiScorer([0, 0]) if multi else fs.FrontierScorer(device=0)
     host.set_option("cloud.order", 0)
-    dev.set_option("cloud.order", 1)
+    dev.set_option("cloud.order", 2)
     for s in (host, dev):
         s.upload_landmarks(lm)
         s.lookup_generate()
@@ -103,7 +103,7 @@ def test_device_order_is_a_function_of_the_input_and_works_on_every_member(fs):
     host, multi = _pair(fs, lm, 1.0, multi=True)
     one = fs.FrontierScorer(device=0)
     try:
-        one.set_option("cloud.order", 1); one.set_option("fim.learn", 0)
+        one.set_option("cloud.order", 2); one.set_option("fim.learn", 0)
         one.lookup_generate(); one.set_fim_params(14.0, 1.0)
         one.upload_landmarks(lm)
         one.get_counter(0, reset=True)

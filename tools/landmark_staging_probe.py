@@ -28,7 +28,7 @@ def child():
         lm = np.ascontiguousarray(rng.uniform(-12.0, 12.0, size=(m, 3)).astype(np.float32))
         lm[:, 2] = rng.uniform(0.0, 2.5, size=m)
         s = fs.FrontierScorer(device=0)
-        s.set_option("cloud.order", 1 if os.environ.get("FS_PROBE_DEVICE_ORDER") else 0)
+        s.set_option("cloud.order", 2 if os.environ.get("FS_PROBE_DEVICE_ORDER") else 0)
         ts = []
         for _ in range(11):
             t0 = time.perf_counter()
