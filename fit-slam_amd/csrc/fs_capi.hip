@@ -270,6 +270,7 @@ struct fs_ctx {
     DevBuf<float> d_cloud_raw;
     DevBuf<int32_t> d_cloud_perm, d_cloud_bounds;
     DevBuf<uint64_t> d_cloud_keys;
+    DevBuf<uint32_t> d_cloud_bbox;
     DevBuf<char> d_cloud_temp;
     bool opt_sort = true;
     bool opt_sort_reverse = false; // development: blocks in reverse Morton order (order-sensitivity measurements)
@@ -846,7 +847,7 @@ void fs_ctx_destroy(fs_ctx *c)
     if (c->rank_scratch) (void)hipFree(c->rank_scratch);
     if (c->sort_scratch) (void)hipFree(c->sort_scratch);
     c->d_perm.release(); c->h_in.release(); c->h_out.release(); c->d_in.release(); c->h_gin.release(); c->d_gin.release(); c->h_fin.release(); c->h_win.release(); c->d_win.release();
-    c->d_cloud_raw.release(); c->d_cloud_perm.release(); c->d_cloud_bounds.release(); c->d_cloud_keys.release(); c->d_cloud_temp.release();
+    c->d_cloud_raw.release(); c->d_cloud_perm.release(); c->d_cloud_bounds.release(); c->d_cloud_keys.release(); c->d_cloud_temp.release(); c->d_cloud_bbox.release();
     c->d_seg_start.release(); c->d_seg_end.release(); c->d_tri.release(); c->d_seg_ok.release(); c->d_seg_hit.release();
     c->d_mask.release(); c->d_brick_cells.release(); c->d_seg_traced.release(); c->d_seg_unknown.release();
     c->d_seg_all.release(); c->d_brick_xyz.release(); c->d_bad.release(); c->d_count.release();
@@ -1588,6 +1589,7 @@ static int upload_landmarks_device_order(fs_ctx *c, const float *xyz, int32_t m)
     FS_HIP(c, c->d_cloud_keys.ensure(2 * (size_t)std::max(n_usable, 1)));
     FS_HIP(c, c->d_cloud_bounds.ensure(std::max<size_t>(bounds.size(), 1)));
     FS_HIP(c, c->d_cloud_temp.ensure(std::max<size_t>(temp_bytes, 256)));
+    FS_HIP(c, c->d_cloud_bbox.ensure(fs_cloud_top_bbox_words()));
     if (m > 0) FS_HIP(c, hipMemcpyAsync(c->d_cloud_raw.p, xyz, sizeof(float) * 3 * (size_t)m, hipMemcpyHostToDevice, c->stream));
     if (!bounds.empty()) FS_HIP(c, hipMemcpyAsync(c->d_cloud_bounds.p, bounds.data(), sizeof(int32_t) * bounds.size(), hipMemcpyHostToDevice, c->stream));
     int32_t *perm_a = c->d_cloud_perm.p, *perm_b = perm_a + std::max(n_usable, 1);
@@ -1595,7 +1597,7 @@ static int upload_landmarks_device_order(fs_ctx *c, const float *xyz, int32_t m)
     else if (n_usable > 0) FS_HIP(c, hipMemcpyAsync(perm_a, usable.data(), sizeof(int32_t) * (size_t)n_usable, hipMemcpyHostToDevice, c->stream));
     int32_t *perm = perm_a;
     FS_HIP(c, fs_cloud_order_device(c->d_cloud_raw.p, n_usable, c->d_cloud_bounds.p, level_off, level_nodes, perm_a, perm_b, c->d_cloud_keys.p,
-                                    c->d_cloud_keys.p + std::max(n_usable, 1), c->d_cloud_temp.p, temp_bytes, c->stream, &perm));
+                                    c->d_cloud_keys.p + std::max(n_usable, 1), c->d_cloud_temp.p, temp_bytes, c->d_cloud_bbox.p, c->stream, &perm));
     FS_HIP(c, fs_cloud_finish(c->d_cloud_raw.p, perm, n_usable, n_chunks, c->d_lx.p, c->d_ly.p, c->d_lz.p, c->d_spheres.p, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));                  // (the caller's cloud and the vectors above are read until here)
     if (c->d_cloud_raw.cap > ((size_t)16 << 20)) { c->d_cloud_raw.release(); c->d_cloud_perm.release(); c->d_cloud_keys.release(); c->d_cloud_temp.release(); }

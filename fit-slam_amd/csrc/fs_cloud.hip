@@ -71,6 +71,81 @@ void fs_cloud_keys_kernel(const float *__restrict__ raw, const int32_t *__restri
     for (int p = lo + (int)threadIdx.x; p < hi; p += blockDim.x) keys[p] = node | sortable(raw[3 * (size_t)perm[p] + ax]);
 }
 
+// The top levels — few nodes, each a large share of the cloud — in two launches instead: every node's bounding box by many
+// workgroups (a slice each, folded into the node's six words with atomic min / max on the sortable form), then one thread per
+// landmark finds its node, the node's longest axis (the same rule) and writes the key.  One workgroup per node took 131 us for the
+// root of a 100 k-landmark cloud and half of that for each of the next levels (profiles/r05/cloud_order_kernel_stats.csv).
+#define FS_CLOUD_TOP_NODES 32                                      // levels of up to this many nodes take the two-launch form
+#define FS_CLOUD_TOP_LEVELS 6                                      // ... 1, 2, 4, 8, 16, 32 nodes: the first six levels at most
+
+__device__ __forceinline__ float unsortable(uint32_t u)
+{
+    return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+__global__ __launch_bounds__(256)
+void fs_cloud_top_bbox_kernel(const float *__restrict__ raw, const int32_t *__restrict__ perm, const int32_t *__restrict__ bounds,
+                              uint32_t *__restrict__ bbox /* [nodes][6]: min x y z, max x y z, sortable */)
+{
+    __shared__ float red[6][4];
+    const int j = blockIdx.y;
+    const int lo = bounds[j], hi = bounds[j + 1];
+    if (hi - lo <= FS_CHUNK) return;
+    const int per = (hi - lo + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int a0 = lo + (int)blockIdx.x * per, a1 = min(hi, a0 + per);
+    if (a0 >= a1) return;
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int p = a0 + (int)threadIdx.x; p < a1; p += blockDim.x) {
+        const float *q = raw + 3 * (size_t)perm[p];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { blo[a] = fminf(blo[a], q[a]); bhi[a] = fmaxf(bhi[a], q[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+        for (int d = 32; d >= 1; d >>= 1) { blo[a] = fminf(blo[a], __shfl_xor(blo[a], d)); bhi[a] = fmaxf(bhi[a], __shfl_xor(bhi[a], d)); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { red[a][wave] = blo[a]; red[3 + a][wave] = bhi[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float v = red[a][0];
+        for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, red[a][w]) : fmaxf(v, red[a][w]);
+        // (a slice whose threads all idled keeps +-inf: harmless under min / max)
+        if (a < 3) atomicMin(&bbox[6 * j + a], sortable(v));
+        else atomicMax(&bbox[6 * j + a], sortable(v));
+    }
+}
+
+__global__ void fs_cloud_top_reset_kernel(uint32_t *bbox, int n_words)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) bbox[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+}
+
+__global__ __launch_bounds__(256)
+void fs_cloud_top_keys_kernel(const float *__restrict__ raw, const int32_t *__restrict__ perm, const int32_t *__restrict__ bounds, int nodes,
+                              const uint32_t *__restrict__ bbox, int32_t n_usable, uint64_t *__restrict__ keys)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_usable) return;
+    int j = 0;                                                     // the node that holds position p: bounds[j] <= p < bounds[j + 1]
+    for (int step = FS_CLOUD_TOP_NODES >> 1; step >= 1; step >>= 1)
+        if (j + step < nodes && bounds[j + step] <= p) j += step;
+    const int lo = bounds[j], hi = bounds[j + 1];
+    const uint64_t node = (uint64_t)(uint32_t)j << 32;
+    if (hi - lo <= FS_CHUNK) { keys[p] = node | (uint32_t)(p - lo); return; }
+    float l[3], h[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { l[a] = unsortable(bbox[6 * j + a]); h[a] = unsortable(bbox[6 * j + 3 + a]); }
+    int ax = 0;                                                    // the host form's rule, word for word (fs_stage_landmarks)
+    if (h[1] - l[1] > h[ax] - l[ax]) ax = 1;
+    if (h[2] - l[2] > h[ax] - l[ax]) ax = 2;
+    keys[p] = node | sortable(raw[3 * (size_t)perm[p] + ax]);
+}
+
 __global__ void fs_cloud_iota_kernel(int32_t *perm, int32_t n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,6 +227,8 @@ void fs_cloud_levels(int32_t n_usable, std::vector<int32_t> &bounds, std::vector
     }
 }
 
+size_t fs_cloud_top_bbox_words() { return (size_t)6 * FS_CLOUD_TOP_NODES * FS_CLOUD_TOP_LEVELS; }
+
 size_t fs_cloud_sort_temp_bytes(int32_t n, hipStream_t s)
 {
     size_t bytes = 0;
@@ -164,12 +241,23 @@ size_t fs_cloud_sort_temp_bytes(int32_t n, hipStream_t s)
 // perm_a holds the starting order of the usable landmarks (input order); returns the final order in *perm_out (one of the two buffers)
 hipError_t fs_cloud_order_device(const float *d_raw, int32_t n_usable, const int32_t *d_bounds, const std::vector<int32_t> &level_off,
                                  const std::vector<int32_t> &level_nodes, int32_t *d_perm_a, int32_t *d_perm_b, uint64_t *d_keys_a,
-                                 uint64_t *d_keys_b, void *d_temp, size_t temp_bytes, hipStream_t s, int32_t **perm_out)
+                                 uint64_t *d_keys_b, void *d_temp, size_t temp_bytes, uint32_t *d_top_bbox, hipStream_t s, int32_t **perm_out)
 {
     int32_t *pin = d_perm_a, *pout = d_perm_b;
     for (size_t L = 0; L < level_off.size(); ++L) {
         const int32_t nodes = level_nodes[L];
-        hipLaunchKernelGGL(fs_cloud_keys_kernel, dim3(nodes), dim3(nodes <= 8 ? 1024 : nodes <= 64 ? 512 : 256), 0, s, d_raw, pin, d_bounds + level_off[L], d_keys_a);
+        if (nodes <= FS_CLOUD_TOP_NODES && (int)L < FS_CLOUD_TOP_LEVELS && d_top_bbox) {
+            const int slices = std::max(1, std::min(256, (n_usable / nodes + 2047) / 2048));
+            if (L == 0) {                                        // every top level's boxes start at (+max, -max): one launch for all of them
+                const int words = 6 * FS_CLOUD_TOP_NODES * FS_CLOUD_TOP_LEVELS;
+                hipLaunchKernelGGL(fs_cloud_top_reset_kernel, dim3((words + 255) / 256), dim3(256), 0, s, d_top_bbox, words);
+            }
+            uint32_t *bbox = d_top_bbox + 6 * FS_CLOUD_TOP_NODES * L;
+            hipLaunchKernelGGL(fs_cloud_top_bbox_kernel, dim3(slices, nodes), dim3(256), 0, s, d_raw, pin, d_bounds + level_off[L], bbox);
+            hipLaunchKernelGGL(fs_cloud_top_keys_kernel, dim3((n_usable + 255) / 256), dim3(256), 0, s, d_raw, pin, d_bounds + level_off[L], nodes, bbox, n_usable, d_keys_a);
+        } else {
+            hipLaunchKernelGGL(fs_cloud_keys_kernel, dim3(nodes), dim3(nodes <= 8 ? 1024 : nodes <= 64 ? 512 : 256), 0, s, d_raw, pin, d_bounds + level_off[L], d_keys_a);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         int node_bits = 1;
