@@ -1577,10 +1577,11 @@ static int upload_landmarks_device_order(fs_ctx *c, const float *xyz, int32_t m)
         for (int32_t i = 0; i < m; ++i) if (ok(i)) usable.push_back(i);
     }
     const bool all_usable = n_usable == m;
+    c->have_lm = false;                                          // (until the new cloud is whole: an error on the way leaves no cloud, not half of one)
     const int32_t n_chunks = std::max<int32_t>(1, (m + FS_CHUNK - 1) / FS_CHUNK);
     const size_t mp = (size_t)n_chunks * FS_CHUNK;
-    std::vector<int32_t> bounds, level_off, level_nodes;
-    fs_cloud_levels(n_usable, bounds, level_off, level_nodes);
+    std::vector<int32_t> bounds, level_off, level_nodes, level_largest;
+    fs_cloud_levels(n_usable, bounds, level_off, level_nodes, level_largest);
     const size_t temp_bytes = fs_cloud_sort_temp_bytes(n_usable, c->stream);
     FS_HIP(c, c->d_lx.ensure(mp)); FS_HIP(c, c->d_ly.ensure(mp)); FS_HIP(c, c->d_lz.ensure(mp));
     FS_HIP(c, c->d_spheres.ensure((size_t)n_chunks * 4));
@@ -1596,7 +1597,7 @@ static int upload_landmarks_device_order(fs_ctx *c, const float *xyz, int32_t m)
     if (all_usable) FS_HIP(c, fs_cloud_iota(perm_a, n_usable, c->stream));
     else if (n_usable > 0) FS_HIP(c, hipMemcpyAsync(perm_a, usable.data(), sizeof(int32_t) * (size_t)n_usable, hipMemcpyHostToDevice, c->stream));
     int32_t *perm = perm_a;
-    FS_HIP(c, fs_cloud_order_device(c->d_cloud_raw.p, n_usable, c->d_cloud_bounds.p, level_off, level_nodes, perm_a, perm_b, c->d_cloud_keys.p,
+    FS_HIP(c, fs_cloud_order_device(c->d_cloud_raw.p, n_usable, c->d_cloud_bounds.p, level_off, level_nodes, level_largest, perm_a, perm_b, c->d_cloud_keys.p,
                                     c->d_cloud_keys.p + std::max(n_usable, 1), c->d_cloud_temp.p, temp_bytes, c->d_cloud_bbox.p, c->stream, &perm));
     FS_HIP(c, fs_cloud_finish(c->d_cloud_raw.p, perm, n_usable, n_chunks, c->d_lx.p, c->d_ly.p, c->d_lz.p, c->d_spheres.p, c->stream));
     FS_HIP(c, hipStreamSynchronize(c->stream));                  // (the caller's cloud and the vectors above are read until here)

@@ -14,6 +14,7 @@
 #include <algorithm>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 namespace {
 
@@ -25,18 +26,20 @@ __device__ __forceinline__ uint32_t sortable(float v)
 
 // One workgroup per node of the level: bounding box of its landmarks -> longest axis -> keys.  A node that no longer splits
 // (<= 64 landmarks) writes keys that leave it where it is.
+// (KEY = uint32_t: the key is the coordinate word alone — for the levels whose nodes are sorted as SEGMENTS, each by itself)
+template <typename KEY>
 __global__ __launch_bounds__(1024)
 void fs_cloud_keys_kernel(const float *__restrict__ raw, const int32_t *__restrict__ perm, const int32_t *__restrict__ bounds,
-                          uint64_t *__restrict__ keys)
+                          KEY *__restrict__ keys)
 {
     __shared__ float red[6][16];
     __shared__ int s_axis;
     const int j = blockIdx.x;
     const int lo = bounds[j], hi = bounds[j + 1];
     const int n = hi - lo;
-    const uint64_t node = (uint64_t)(uint32_t)j << 32;
+    const KEY node = sizeof(KEY) == 8 ? (KEY)((uint64_t)(uint32_t)j << 32) : (KEY)0;
     if (n <= FS_CHUNK) {
-        for (int p = lo + (int)threadIdx.x; p < hi; p += blockDim.x) keys[p] = node | (uint32_t)(p - lo);
+        for (int p = lo + (int)threadIdx.x; p < hi; p += blockDim.x) keys[p] = node | (KEY)(uint32_t)(p - lo);
         return;
     }
     float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -68,7 +71,7 @@ void fs_cloud_keys_kernel(const float *__restrict__ raw, const int32_t *__restri
     }
     __syncthreads();
     const int ax = s_axis;
-    for (int p = lo + (int)threadIdx.x; p < hi; p += blockDim.x) keys[p] = node | sortable(raw[3 * (size_t)perm[p] + ax]);
+    for (int p = lo + (int)threadIdx.x; p < hi; p += blockDim.x) keys[p] = node | (KEY)sortable(raw[3 * (size_t)perm[p] + ax]);
 }
 
 // The top levels — few nodes, each a large share of the cloud — in two launches instead: every node's bounding box by many
@@ -76,6 +79,7 @@ void fs_cloud_keys_kernel(const float *__restrict__ raw, const int32_t *__restri
 // landmark finds its node, the node's longest axis (the same rule) and writes the key.  One workgroup per node took 131 us for the
 // root of a 100 k-landmark cloud and half of that for each of the next levels (profiles/r05/cloud_order_kernel_stats.csv).
 #define FS_CLOUD_TOP_NODES 32                                      // levels of up to this many nodes take the two-launch form
+#define FS_CLOUD_SEGMENT_MAX 4096                                  // levels whose largest node is at most this sort node by node (segments)
 #define FS_CLOUD_TOP_LEVELS 6                                      // ... 1, 2, 4, 8, 16, 32 nodes: the first six levels at most
 
 __device__ __forceinline__ float unsortable(uint32_t u)
@@ -199,15 +203,18 @@ void fs_cloud_spheres_kernel(const float *__restrict__ lx, const float *__restri
 
 }  // namespace
 
-// Every level's node boundaries, concatenated: level L holds level_nodes[L] + 1 ascending positions from 0 to n_usable.
-void fs_cloud_levels(int32_t n_usable, std::vector<int32_t> &bounds, std::vector<int32_t> &level_off, std::vector<int32_t> &level_nodes)
+// Every level's node boundaries, concatenated: level L holds level_nodes[L] + 1 ascending positions from 0 to n_usable; its largest
+// node has level_largest[L] landmarks.
+void fs_cloud_levels(int32_t n_usable, std::vector<int32_t> &bounds, std::vector<int32_t> &level_off, std::vector<int32_t> &level_nodes,
+                     std::vector<int32_t> &level_largest)
 {
-    bounds.clear(); level_off.clear(); level_nodes.clear();
+    bounds.clear(); level_off.clear(); level_nodes.clear(); level_largest.clear();
     std::vector<int32_t> cur{0, n_usable};
     for (;;) {
-        bool splits = false;
-        for (size_t j = 0; j + 1 < cur.size(); ++j) splits |= (cur[j + 1] - cur[j]) > FS_CHUNK;
-        if (!splits) break;
+        int32_t largest = 0;
+        for (size_t j = 0; j + 1 < cur.size(); ++j) largest = std::max(largest, cur[j + 1] - cur[j]);
+        if (largest <= FS_CHUNK) break;
+        level_largest.push_back(largest);
         level_off.push_back((int32_t)bounds.size());
         level_nodes.push_back((int32_t)cur.size() - 1);
         bounds.insert(bounds.end(), cur.begin(), cur.end());
@@ -231,16 +238,19 @@ size_t fs_cloud_top_bbox_words() { return (size_t)6 * FS_CLOUD_TOP_NODES * FS_CL
 
 size_t fs_cloud_sort_temp_bytes(int32_t n, hipStream_t s)
 {
-    size_t bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
-                                  (size_t)std::max(n, 1), 0, 64, s) != hipSuccess)
+    size_t bytes = 0, seg = 0;
+    const size_t size = (size_t)std::max(n, 1);
+    if (rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, size, 0, 64, s) != hipSuccess)
         return 0;
-    return bytes;
+    if (rocprim::segmented_radix_sort_pairs(nullptr, seg, (uint32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned int)size,
+                                            (unsigned int)(size / FS_CHUNK + 2), (const int32_t *)nullptr, (const int32_t *)nullptr, 0, 32, s) != hipSuccess)
+        return 0;
+    return std::max(bytes, seg);
 }
 
 // perm_a holds the starting order of the usable landmarks (input order); returns the final order in *perm_out (one of the two buffers)
 hipError_t fs_cloud_order_device(const float *d_raw, int32_t n_usable, const int32_t *d_bounds, const std::vector<int32_t> &level_off,
-                                 const std::vector<int32_t> &level_nodes, int32_t *d_perm_a, int32_t *d_perm_b, uint64_t *d_keys_a,
+                                 const std::vector<int32_t> &level_nodes, const std::vector<int32_t> &level_largest, int32_t *d_perm_a, int32_t *d_perm_b, uint64_t *d_keys_a,
                                  uint64_t *d_keys_b, void *d_temp, size_t temp_bytes, uint32_t *d_top_bbox, hipStream_t s, int32_t **perm_out)
 {
     int32_t *pin = d_perm_a, *pout = d_perm_b;
@@ -255,8 +265,22 @@ hipError_t fs_cloud_order_device(const float *d_raw, int32_t n_usable, const int
             uint32_t *bbox = d_top_bbox + 6 * FS_CLOUD_TOP_NODES * L;
             hipLaunchKernelGGL(fs_cloud_top_bbox_kernel, dim3(slices, nodes), dim3(256), 0, s, d_raw, pin, d_bounds + level_off[L], bbox);
             hipLaunchKernelGGL(fs_cloud_top_keys_kernel, dim3((n_usable + 255) / 256), dim3(256), 0, s, d_raw, pin, d_bounds + level_off[L], nodes, bbox, n_usable, d_keys_a);
+        } else if (level_largest[L] <= FS_CLOUD_SEGMENT_MAX) {
+            // the deep levels — many nodes, each of a few thousand landmarks at most — sort every node as a SEGMENT of its own (one
+            // launch, a workgroup per node) on the coordinate word alone: a sort of the whole array is a block sort and seven merge
+            // passes at 100 k pairs, 63 us per level (profiles/r05/cloud_order_kernel_stats.csv)
+            uint32_t *k32_in = reinterpret_cast<uint32_t *>(d_keys_a), *k32_out = reinterpret_cast<uint32_t *>(d_keys_b);
+            hipLaunchKernelGGL(fs_cloud_keys_kernel<uint32_t>, dim3(nodes), dim3(256), 0, s, d_raw, pin, d_bounds + level_off[L], k32_in);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            size_t bytes = temp_bytes;
+            e = rocprim::segmented_radix_sort_pairs(d_temp, bytes, k32_in, k32_out, pin, pout, (unsigned int)n_usable, (unsigned int)nodes,
+                                                    d_bounds + level_off[L], d_bounds + level_off[L] + 1, 0, 32, s);
+            if (e != hipSuccess) return e;
+            std::swap(pin, pout);
+            continue;
         } else {
-            hipLaunchKernelGGL(fs_cloud_keys_kernel, dim3(nodes), dim3(nodes <= 8 ? 1024 : nodes <= 64 ? 512 : 256), 0, s, d_raw, pin, d_bounds + level_off[L], d_keys_a);
+            hipLaunchKernelGGL(fs_cloud_keys_kernel<uint64_t>, dim3(nodes), dim3(nodes <= 8 ? 1024 : nodes <= 64 ? 512 : 256), 0, s, d_raw, pin, d_bounds + level_off[L], d_keys_a);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

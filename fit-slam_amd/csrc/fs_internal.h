@@ -143,11 +143,12 @@ int fs_upload_staged_landmarks(fs_ctx *c, const FsStagedCloud &st);
 // ... and the same ordering computed on the device ("cloud.order", fs_cloud.hip): every level's node boundaries (a function of the
 // number of usable landmarks alone), the level loop (keys kernel + one stable radix sort per level), the SoA gather and the spheres
 bool fs_ctx_cloud_on_device(const fs_ctx *c, int32_t m);
-void fs_cloud_levels(int32_t n_usable, std::vector<int32_t> &bounds, std::vector<int32_t> &level_off, std::vector<int32_t> &level_nodes);
+void fs_cloud_levels(int32_t n_usable, std::vector<int32_t> &bounds, std::vector<int32_t> &level_off, std::vector<int32_t> &level_nodes,
+                     std::vector<int32_t> &level_largest);
 size_t fs_cloud_sort_temp_bytes(int32_t n, hipStream_t s);
 hipError_t fs_cloud_iota(int32_t *d_perm, int32_t n, hipStream_t s);
 hipError_t fs_cloud_order_device(const float *d_raw, int32_t n_usable, const int32_t *d_bounds, const std::vector<int32_t> &level_off,
-                                 const std::vector<int32_t> &level_nodes, int32_t *d_perm_a, int32_t *d_perm_b, uint64_t *d_keys_a,
+                                 const std::vector<int32_t> &level_nodes, const std::vector<int32_t> &level_largest, int32_t *d_perm_a, int32_t *d_perm_b, uint64_t *d_keys_a,
                                  uint64_t *d_keys_b, void *d_temp, size_t temp_bytes, uint32_t *d_top_bbox, hipStream_t s, int32_t **perm_out);
 size_t fs_cloud_top_bbox_words();   // scratch of the top levels' bounding boxes (d_top_bbox; nullptr: one workgroup per node at every level)
 hipError_t fs_cloud_finish(const float *d_raw, const int32_t *d_perm, int32_t n_usable, int32_t n_chunks, float *d_lx, float *d_ly, float *d_lz,
