@@ -56,7 +56,7 @@ int  fs_kernel_time(fs_ctx *ctx, int kind, double *total_ms, int64_t *launches);
  * into mapped page-locked memory and the host adds them after the synchronisation (same additions, same order as the finish
  * kernel); the HBM-tier and finish launches follow only if an item ran out of table.  0 = always three launches.
  * "cloud.order" (default 1): where fs_upload_landmarks puts the cloud into the leaf order of the k-d tree with 64 landmarks per leaf —
- * 2 on the device (one keys kernel + one stable radix sort per level, fs_cloud.hip: 0.9 ms at 100 k landmarks, 2.5 ms at 500 k),
+ * 2 on the device (one keys kernel + one sort per level, fs_cloud.hip: 0.7 ms at 100 k landmarks, 1.9 ms at 500 k),
  * 0 on the host (its top levels on threads of their own: 4.4 / 20.2 ms; FS_KD_THREADS=1 in the environment keeps it on the calling
  * thread: 13.3 / 78.9 ms), 1 on the device from 4096 landmarks on (a level costs the device its launches whatever its size: a 2 k
  * cloud takes 0.06 ms on the host, 0.18 ms on the device).  Same split rule; tied coordinates may land in different leaves, so the
